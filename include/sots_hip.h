@@ -1,0 +1,181 @@
+/*
+ * sots_hip.h -- C-ABI of libsots_hip.so, the MI355X (gfx950) backend for the
+ * per-generation evolutionary FM sound-matching loop.
+ *
+ * This is the drop-in boundary: Evolutionary_Strategy_HIP (C++, host/) and the
+ * ctypes binding (capi.py) sit on top of exactly these entry points.  Plain
+ * pointers and sizes only; no C++ or torch types cross it.  One context is used
+ * from one host thread at a time (the reference's objects are single-threaded
+ * too).  Every call returns SOTS_OK (0) or a negative code;
+ * sots_last_error() gives the text.  All file:line citations are relative to the
+ * reference tree.
+ *
+ * Population state, as in the reference's device buffer set
+ * (Evolutionary_Strategy_OpenCL.hpp:60-63,278-292):
+ *   value, step : float[2][P][D]   two rotation halves, one row per individual
+ *   fitness     : float[2][P]
+ *   audio       : float[P][N]
+ *   spectrum    : float[P][N+8]    interleaved complex, N/2+4 bins per row,
+ *                                  bins 0..N/2 valid (clFFT layout, :164-168)
+ *   target      : float[N/2]
+ * P = numParents + numOffspring, D = numDimensions, N = 2^audioLengthLog2.
+ */
+#ifndef SOTS_HIP_H
+#define SOTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOTS_MAX_DIMS 16
+#define SOTS_WAVETABLE_SIZE 32768u /* Evolutionary_Strategy.hpp:197 */
+#define SOTS_SAMPLE_RATE 44100u    /* Evolutionary_Strategy.hpp:196 */
+
+enum sots_status {
+    SOTS_OK = 0,
+    SOTS_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    SOTS_ERR_HIP = -2,       /* a HIP runtime call failed */
+    SOTS_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    SOTS_ERR_SIZE = -4,      /* caller buffer too small / wrong byte count */
+    SOTS_ERR_STATE = -5      /* call out of order (e.g. no target set) */
+};
+
+/* Which FM voice synthesisePopulation runs; numDimensions must match. */
+enum sots_synth_kind {
+    SOTS_SYNTH_2OP = 0,        /* D=4,  ocl_program.cl:280-330, Evolutionary_Strategy.hpp:368-402 */
+    SOTS_SYNTH_3OP_SERIES = 1, /* D=6,  ocl_program.cl:332-386, Evolutionary_Strategy.hpp:403-449 */
+    SOTS_SYNTH_TRIPLE_PAR = 2, /* D=12, ocl_program.cl:388-443, Evolutionary_Strategy.hpp:450-495 */
+    SOTS_SYNTH_4OP_SERIES = 3  /* D=8,  build-defined 4-operator series chain (BASELINE config 4) */
+};
+
+/* Stage ids, in the order of the reference's kernelNames_
+ * (Evolutionary_Strategy_OpenCL.hpp:54,117). */
+enum sots_stage {
+    SOTS_STAGE_INIT = 0,
+    SOTS_STAGE_RECOMBINE = 1,
+    SOTS_STAGE_MUTATE = 2,
+    SOTS_STAGE_SYNTHESISE = 3,
+    SOTS_STAGE_WINDOW = 4,
+    SOTS_STAGE_FFT = 5,
+    SOTS_STAGE_FITNESS = 6,
+    SOTS_STAGE_SORT = 7,
+    SOTS_STAGE_ROTATE = 8,
+    /* kernels of the fused generation loop (sots_execute_generations) */
+    SOTS_STAGE_FUSED_VARIATION = 9, /* recombine + mutate */
+    SOTS_STAGE_FUSED_SYNTH = 10,    /* synthesise + window */
+    SOTS_STAGE_FUSED_SPECTRAL = 11, /* FFT + fitness */
+    SOTS_STAGE_COUNT = 12
+};
+
+/* Replaces Evolutionary_Strategy_OpenCL_Arguments
+ * (Evolutionary_Strategy_OpenCL.hpp:25-38) + Evolutionary_Strategy_Arguments
+ * (Evolutionary_Strategy.hpp:579-589). */
+typedef struct sots_config {
+    uint32_t struct_size;       /* = sizeof(sots_config) */
+    uint32_t num_parents;       /* es_args.pop.numParents */
+    uint32_t num_offspring;     /* es_args.pop.numOffspring */
+    uint32_t num_dimensions;    /* es_args.pop.numDimensions */
+    uint32_t audio_length_log2; /* es_args.audioLengthLog2, 9..13 */
+    uint32_t num_generations;   /* es_args.numGenerations */
+    uint32_t synth_kind;        /* enum sots_synth_kind */
+    uint32_t workgroup_size;    /* workgroupX: the recombination block (WRKGRPSIZE in ocl_program.cl:86-148) */
+    int32_t device;             /* HIP device ordinal (replaces deviceType) */
+    uint32_t gid_base;          /* global id of individual 0 (island offset for the PRNG) */
+    uint64_t seed;              /* PRNG key (replaces the wall-clock seed, ...OpenCL.hpp:383) */
+    float param_min[SOTS_MAX_DIMS]; /* es_args.paramMin */
+    float param_max[SOTS_MAX_DIMS]; /* es_args.paramMax */
+} sots_config;
+
+typedef struct sots_ctx sots_ctx;
+
+/* ---- lifetime (replaces Evolutionary_Strategy_OpenCL::init, ...OpenCL.hpp:138-150) ---- */
+int sots_create(const sots_config *cfg, sots_ctx **out);
+void sots_destroy(sots_ctx *ctx);
+/* text of the last failure on ctx (or of the last failed sots_create when ctx == NULL) */
+const char *sots_last_error(const sots_ctx *ctx);
+/* run every later launch/copy on this hipStream_t (NULL = the context's own stream) */
+int sots_set_stream(sots_ctx *ctx, void *hip_stream);
+int sots_synchronize(sots_ctx *ctx);
+
+/* ---- target (replaces setTargetAudio, ...OpenCL.hpp:563-570; Objective::calculateFFT,
+ *      Evolutionary_Strategy.hpp:524-542) ---- */
+int sots_set_target_audio(sots_ctx *ctx, const float *audio, uint32_t num_samples);
+int sots_set_target_spectrum(sots_ctx *ctx, const float *magnitudes, uint32_t num_bins);
+
+/* ---- population (initPopulationCL ...OpenCL.hpp:369-378; write/readPopulationData :403-430) ---- */
+int sots_init_population(sots_ctx *ctx, uint32_t chunk_index);
+/* any pointer may be NULL; byte counts must equal P*D*4 (values, steps) and P*4 (fitness).
+ * Reads and writes address the CURRENT rotation half. */
+int sots_write_population(sots_ctx *ctx, const float *values, size_t values_bytes,
+                          const float *steps, size_t steps_bytes,
+                          const float *fitness, size_t fitness_bytes);
+int sots_read_population(sots_ctx *ctx, float *values, size_t values_bytes,
+                         float *steps, size_t steps_bytes,
+                         float *fitness, size_t fitness_bytes);
+/* the other rotation half (the reference's "output" arrays, main.cpp:241) */
+int sots_read_population_other(sots_ctx *ctx, float *values, size_t values_bytes,
+                               float *steps, size_t steps_bytes,
+                               float *fitness, size_t fitness_bytes);
+
+/* ---- synthesiser buffers (write/readSynthesizerData, ...OpenCL.hpp:436-453) ----
+ * audio: P*N*4 bytes; spectrum: P*(N+8)*4 bytes; target: (N/2)*4 bytes; NULL skips. */
+int sots_write_synth(sots_ctx *ctx, const float *audio, size_t audio_bytes,
+                     const float *spectrum, size_t spectrum_bytes);
+int sots_read_synth(sots_ctx *ctx, float *audio, size_t audio_bytes,
+                    float *spectrum, size_t spectrum_bytes,
+                    float *target, size_t target_bytes);
+
+/* ---- the nine stages, one launch sequence each (executeGeneration, ...OpenCL.hpp:471-541) ---- */
+int sots_stage_recombine(sots_ctx *ctx);
+int sots_stage_mutate(sots_ctx *ctx);
+int sots_stage_synthesise(sots_ctx *ctx);
+int sots_stage_window(sots_ctx *ctx);
+int sots_stage_fft(sots_ctx *ctx);
+int sots_stage_fitness(sots_ctx *ctx);
+int sots_stage_sort(sots_ctx *ctx);
+int sots_stage_rotate(sots_ctx *ctx);
+
+/* stage-separated generation: the eight stages above in reference order */
+int sots_execute_generation(sots_ctx *ctx);
+/* n generations of the fused loop (recombine+mutate | synth+window | FFT+fitness |
+ * sort | rotate); same population results as n x sots_execute_generation.
+ * (executeAllGenerations, ...OpenCL.hpp:542-547) */
+int sots_execute_generations(sots_ctx *ctx, uint32_t n);
+
+int sots_get_generation(const sots_ctx *ctx, uint32_t *generation);
+int sots_set_generation(sots_ctx *ctx, uint32_t generation);
+
+/* ---- per-stage device timing (feeds Benchmarker::addTimer, Benchmarker.hpp:109-130) ---- */
+int sots_timing_enable(sots_ctx *ctx, int enabled);
+int sots_timing_reset(sots_ctx *ctx);
+/* sum of hipEvent-measured durations and the number of launches of that stage
+ * since the last reset; synchronises the stream */
+int sots_stage_time_ms(sots_ctx *ctx, int stage, double *total_ms, uint64_t *count);
+
+/* ---- island model (new) ----
+ * A row is [fitness, v0..v(D-1), s0..s(D-1)] = (2D+1) floats.  pack copies the best
+ * n_rows rows of the current (sorted) half; inject overwrites the last n_rows
+ * PARENT rows (numParents-n_rows .. numParents-1) so that immigrants take part
+ * in the next recombination.  *_device take device pointers on this context's
+ * device and run on its stream (no host sync); *_host are blocking. */
+int sots_pack_elites_device(sots_ctx *ctx, void *device_rows, uint32_t n_rows);
+int sots_inject_immigrants_device(sots_ctx *ctx, const void *device_rows, uint32_t n_rows);
+int sots_pack_elites_host(sots_ctx *ctx, float *rows, uint32_t n_rows);
+int sots_inject_immigrants_host(sots_ctx *ctx, const float *rows, uint32_t n_rows);
+
+/* ---- introspection ---- */
+typedef struct sots_info {
+    uint32_t population_length, num_dimensions, audio_length, spectrum_row_floats;
+    uint32_t rotation_index, generation, compute_units, reserved;
+    char device_name[128];
+    char arch[32];
+} sots_info;
+int sots_get_info(const sots_ctx *ctx, sots_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOTS_HIP_H */

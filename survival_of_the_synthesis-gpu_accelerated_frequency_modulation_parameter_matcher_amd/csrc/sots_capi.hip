@@ -1,0 +1,704 @@
+// sots_capi.hip -- the C-ABI of include/sots_hip.h: context, buffers, stage sequencing,
+// device timing.  No CPU fallback exists: every compute entry point launches gfx950 kernels
+// or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sots_hip.h"
+#include "sots_host_math.h"
+#include "sots_kernels.h"
+
+using namespace sots;
+
+namespace {
+
+struct StageClock {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spare;
+    double total_ms = 0.0;
+    uint64_t count = 0;
+};
+
+thread_local std::string g_create_error;
+
+} // namespace
+
+struct sots_ctx {
+    sots_config cfg{};
+    PopDims pd{};
+    MutateConsts mc{};
+    SynthParams sp{};
+    int device = 0;
+    uint32_t num_cus = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint32_t P = 0, D = 0, N = 0, log2n = 0, n_pad = 0;
+    uint32_t rot = 0, generation = 0;
+    bool target_set = false;
+    // device buffers
+    float *values = nullptr, *steps = nullptr, *fitness = nullptr; // [2][P][D], [2][P][D], [2][P]
+    float *audio = nullptr, *spectrum = nullptr, *target = nullptr;
+    float *wavetable = nullptr, *window = nullptr, *rows = nullptr;
+    float2 *twiddle = nullptr;
+    uint64_t *keys = nullptr;
+    uint32_t rows_capacity = 0;
+    // host tables
+    std::vector<double> window64;
+    float window_factor = 1.0f, inv_n = 0.0f, inv_wf = 1.0f;
+    // timing
+    bool timing = false;
+    StageClock clocks[SOTS_STAGE_COUNT];
+    mutable std::string err;
+    char arch[32] = {0};
+    char device_name[128] = {0};
+
+    float *val(uint32_t half) const { return values + (size_t)half * P * D; }
+    float *stp(uint32_t half) const { return steps + (size_t)half * P * D; }
+    float *fit(uint32_t half) const { return fitness + (size_t)half * P; }
+};
+
+namespace {
+
+int fail(const sots_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define SOTS_HIP(ctx, call)                                                                       \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, SOTS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+#define SOTS_REQUIRE_CTX(ctx) \
+    do {                      \
+        if (!(ctx)) return fail(nullptr, SOTS_ERR_INVALID, "null context"); \
+    } while (0)
+
+uint32_t dims_of(uint32_t kind)
+{
+    switch (kind) {
+    case SOTS_SYNTH_2OP: return 4;
+    case SOTS_SYNTH_3OP_SERIES: return 6;
+    case SOTS_SYNTH_TRIPLE_PAR: return 12;
+    case SOTS_SYNTH_4OP_SERIES: return 8;
+    default: return 0;
+    }
+}
+
+int bind_device(const sots_ctx *ctx)
+{
+    SOTS_HIP(ctx, hipSetDevice(ctx->device));
+    return SOTS_OK;
+}
+
+// ---- stage timing -------------------------------------------------------------------
+struct StageScope {
+    sots_ctx *ctx;
+    StageClock *clock = nullptr;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    StageScope(sots_ctx *c, int stage) : ctx(c)
+    {
+        if (!c->timing) return;
+        clock = &c->clocks[stage];
+        if (!clock->spare.empty()) {
+            ev = clock->spare.back();
+            clock->spare.pop_back();
+        } else {
+            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
+                clock = nullptr;
+                return;
+            }
+        }
+        (void)hipEventRecord(ev.first, c->stream);
+    }
+    ~StageScope()
+    {
+        if (!clock) return;
+        (void)hipEventRecord(ev.second, ctx->stream);
+        clock->pending.push_back(ev);
+    }
+};
+
+int drain_clock(sots_ctx *ctx, StageClock &ck)
+{
+    for (auto &ev : ck.pending) {
+        SOTS_HIP(ctx, hipEventSynchronize(ev.second));
+        float ms = 0.0f;
+        SOTS_HIP(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        ck.total_ms += ms;
+        ck.count += 1;
+        ck.spare.push_back(ev);
+    }
+    ck.pending.clear();
+    return SOTS_OK;
+}
+
+// keep the number of live events bounded on long runs
+int maybe_drain(sots_ctx *ctx)
+{
+    if (!ctx->timing) return SOTS_OK;
+    for (auto &ck : ctx->clocks)
+        if (ck.pending.size() >= 4096) {
+            int rc = drain_clock(ctx, ck);
+            if (rc) return rc;
+        }
+    return SOTS_OK;
+}
+
+void free_ctx(sots_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ck : ctx->clocks) {
+        for (auto &ev : ck.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (auto &ev : ck.spare) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    }
+    void *bufs[] = {ctx->values, ctx->steps, ctx->fitness, ctx->audio, ctx->spectrum, ctx->target,
+                    ctx->wavetable, ctx->window, ctx->rows, ctx->twiddle, ctx->keys};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int ensure_rows(sots_ctx *ctx, uint32_t n_rows)
+{
+    if (n_rows <= ctx->rows_capacity) return SOTS_OK;
+    if (ctx->rows) SOTS_HIP(ctx, hipFree(ctx->rows));
+    ctx->rows = nullptr;
+    ctx->rows_capacity = 0;
+    SOTS_HIP(ctx, hipMalloc((void **)&ctx->rows, (size_t)n_rows * (2 * ctx->D + 1) * sizeof(float)));
+    ctx->rows_capacity = n_rows;
+    return SOTS_OK;
+}
+
+int require_target(sots_ctx *ctx)
+{
+    if (!ctx->target_set)
+        return fail(ctx, SOTS_ERR_STATE, "no target: call sots_set_target_audio or sots_set_target_spectrum first");
+    return SOTS_OK;
+}
+
+} // namespace
+
+// =======================================================================================
+extern "C" {
+
+int sots_create(const sots_config *cfg, sots_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, SOTS_ERR_INVALID, "sots_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(sots_config))
+        return fail(nullptr, SOTS_ERR_INVALID, "sots_config.struct_size %u != %zu", cfg->struct_size,
+                    sizeof(sots_config));
+    const uint32_t d = dims_of(cfg->synth_kind);
+    if (d == 0) return fail(nullptr, SOTS_ERR_INVALID, "unknown synth_kind %u", cfg->synth_kind);
+    if (cfg->num_dimensions != d)
+        return fail(nullptr, SOTS_ERR_INVALID, "synth_kind %u needs numDimensions %u, got %u", cfg->synth_kind,
+                    d, cfg->num_dimensions);
+    if (cfg->audio_length_log2 < 9 || cfg->audio_length_log2 > 13)
+        return fail(nullptr, SOTS_ERR_INVALID, "audioLengthLog2 %u outside 9..13", cfg->audio_length_log2);
+    const uint64_t p64 = (uint64_t)cfg->num_parents + cfg->num_offspring;
+    if (cfg->num_parents == 0 || p64 < 2 || p64 > (1ull << 26))
+        return fail(nullptr, SOTS_ERR_INVALID, "population %llu (parents %u) not supported",
+                    (unsigned long long)p64, cfg->num_parents);
+    if (cfg->workgroup_size == 0 || p64 % cfg->workgroup_size != 0)
+        return fail(nullptr, SOTS_ERR_INVALID,
+                    "populationLength %llu must be a multiple of workgroupSize %u (the recombination block)",
+                    (unsigned long long)p64, cfg->workgroup_size);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SOTS_ERR_NO_DEVICE, "no HIP device (%s)", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, SOTS_ERR_NO_DEVICE, "device %d not in 0..%d", cfg->device, ndev - 1);
+
+    sots_ctx *ctx = new sots_ctx();
+    ctx->cfg = *cfg;
+    ctx->device = cfg->device;
+#define CREATE_HIP(call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            int rc_ = fail(nullptr, SOTS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            free_ctx(ctx);                                                                        \
+            return rc_;                                                                           \
+        }                                                                                         \
+    } while (0)
+    CREATE_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    snprintf(ctx->device_name, sizeof ctx->device_name, "%s", prop.name);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(nullptr, SOTS_ERR_NO_DEVICE, "device %d is %s; libsots_hip carries gfx950 code only",
+                      ctx->device, prop.gcnArchName);
+        free_ctx(ctx);
+        return rc;
+    }
+    ctx->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
+    CREATE_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+
+    ctx->P = (uint32_t)p64;
+    ctx->D = d;
+    ctx->log2n = cfg->audio_length_log2;
+    ctx->N = 1u << ctx->log2n;
+    ctx->n_pad = next_pow2(ctx->P < 2 ? 2 : ctx->P);
+    ctx->pd = PopDims{ctx->P, ctx->D, cfg->num_parents, cfg->workgroup_size, cfg->gid_base,
+                      (uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
+    // Evolutionary_Strategy.hpp:611-627
+    const float mpi = (float)3.14159265358979323846;
+    ctx->mc.alpha = 1.4f;
+    ctx->mc.one_over_alpha = 1.f / ctx->mc.alpha;
+    ctx->mc.root_two_over_pi = sqrtf(2.f / (float)mpi);
+    ctx->mc.beta_scale = 1.f / (float)ctx->D;
+    const float beta = sqrtf(ctx->mc.beta_scale);
+    ctx->mc.pow_alpha_beta = powf(ctx->mc.alpha, beta);
+    ctx->mc.pow_inv_alpha_beta = powf(ctx->mc.one_over_alpha, beta);
+    memcpy(ctx->sp.pmin, cfg->param_min, sizeof ctx->sp.pmin);
+    memcpy(ctx->sp.pmax, cfg->param_max, sizeof ctx->sp.pmax);
+
+    const size_t pd_bytes = (size_t)2 * ctx->P * ctx->D * sizeof(float);
+    const size_t audio_bytes = (size_t)ctx->P * ctx->N * sizeof(float);
+    const size_t spec_bytes = (size_t)ctx->P * (ctx->N + 8) * sizeof(float);
+    CREATE_HIP(hipMalloc((void **)&ctx->values, pd_bytes));
+    CREATE_HIP(hipMalloc((void **)&ctx->steps, pd_bytes));
+    CREATE_HIP(hipMalloc((void **)&ctx->fitness, (size_t)2 * ctx->P * sizeof(float)));
+    CREATE_HIP(hipMalloc((void **)&ctx->audio, audio_bytes));
+    CREATE_HIP(hipMalloc((void **)&ctx->spectrum, spec_bytes));
+    CREATE_HIP(hipMalloc((void **)&ctx->target, (size_t)(ctx->N / 2) * sizeof(float)));
+    CREATE_HIP(hipMalloc((void **)&ctx->wavetable, (size_t)SOTS_WAVETABLE_SIZE * sizeof(float)));
+    CREATE_HIP(hipMalloc((void **)&ctx->window, (size_t)ctx->N * sizeof(float)));
+    CREATE_HIP(hipMalloc((void **)&ctx->twiddle, (size_t)ctx->N * sizeof(float2)));
+    CREATE_HIP(hipMalloc((void **)&ctx->keys, (size_t)ctx->n_pad * sizeof(uint64_t)));
+    CREATE_HIP(hipMemsetAsync(ctx->values, 0, pd_bytes, ctx->stream));
+    CREATE_HIP(hipMemsetAsync(ctx->steps, 0, pd_bytes, ctx->stream));
+    CREATE_HIP(hipMemsetAsync(ctx->fitness, 0, (size_t)2 * ctx->P * sizeof(float), ctx->stream));
+    CREATE_HIP(hipMemsetAsync(ctx->audio, 0, audio_bytes, ctx->stream));
+    CREATE_HIP(hipMemsetAsync(ctx->spectrum, 0, spec_bytes, ctx->stream));
+    CREATE_HIP(hipMemsetAsync(ctx->target, 0, (size_t)(ctx->N / 2) * sizeof(float), ctx->stream));
+
+    // host tables the reference also builds on the CPU and uploads (...OpenCL.hpp:315-317)
+    const std::vector<float> table = make_wavetable();
+    ctx->window64 = make_window(ctx->N, &ctx->window_factor);
+    std::vector<float> window32(ctx->N);
+    for (uint32_t i = 0; i < ctx->N; ++i) window32[i] = (float)ctx->window64[i];
+    const std::vector<float> tw = make_twiddles(ctx->N);
+    ctx->inv_n = 1.0f / (float)ctx->N;          // fftOneOverSize
+    ctx->inv_wf = 1.f / ctx->window_factor;     // fftOneOverWindowFactor
+    CREATE_HIP(hipMemcpyAsync(ctx->wavetable, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CREATE_HIP(hipMemcpyAsync(ctx->window, window32.data(), window32.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CREATE_HIP(hipMemcpyAsync(ctx->twiddle, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CREATE_HIP(hipStreamSynchronize(ctx->stream));
+#undef CREATE_HIP
+    *out = ctx;
+    return SOTS_OK;
+}
+
+void sots_destroy(sots_ctx *ctx) { free_ctx(ctx); }
+
+const char *sots_last_error(const sots_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sots_set_stream(sots_ctx *ctx, void *hip_stream)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SOTS_OK;
+}
+
+int sots_synchronize(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SOTS_OK;
+}
+
+// ---- target ---------------------------------------------------------------------------
+int sots_set_target_spectrum(sots_ctx *ctx, const float *magnitudes, uint32_t num_bins)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!magnitudes || num_bins != ctx->N / 2)
+        return fail(ctx, SOTS_ERR_SIZE, "target spectrum needs %u bins, got %u", ctx->N / 2, num_bins);
+    if (int rc = bind_device(ctx)) return rc;
+    SOTS_HIP(ctx, hipMemcpyAsync(ctx->target, magnitudes, (size_t)num_bins * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->target_set = true;
+    return SOTS_OK;
+}
+
+int sots_set_target_audio(sots_ctx *ctx, const float *audio, uint32_t num_samples)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!audio || num_samples < ctx->N)
+        return fail(ctx, SOTS_ERR_SIZE, "target audio needs %u samples, got %u", ctx->N, num_samples);
+    const std::vector<float> mag = target_spectrum(audio, ctx->N, ctx->window64, ctx->window_factor);
+    return sots_set_target_spectrum(ctx, mag.data(), ctx->N / 2);
+}
+
+// ---- population -------------------------------------------------------------------------
+int sots_init_population(sots_ctx *ctx, uint32_t chunk_index)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    ctx->rot = 0; // initPopulationCL, ...OpenCL.hpp:371
+    ctx->generation = 0;
+    {
+        StageScope t(ctx, SOTS_STAGE_INIT);
+        SOTS_HIP(ctx, launch_init_population(ctx->stream, ctx->val(0), ctx->stp(0), ctx->fit(0), ctx->pd, chunk_index));
+    }
+    return maybe_drain(ctx);
+}
+
+static int copy_population(sots_ctx *ctx, uint32_t half, bool to_device, void *values, size_t values_bytes,
+                           void *steps, size_t steps_bytes, void *fitness, size_t fitness_bytes)
+{
+    const size_t pd_bytes = (size_t)ctx->P * ctx->D * sizeof(float), f_bytes = (size_t)ctx->P * sizeof(float);
+    if ((values && values_bytes != pd_bytes) || (steps && steps_bytes != pd_bytes) ||
+        (fitness && fitness_bytes != f_bytes))
+        return fail(ctx, SOTS_ERR_SIZE, "population byte counts must be %zu (values, steps) and %zu (fitness)",
+                    pd_bytes, f_bytes);
+    if (int rc = bind_device(ctx)) return rc;
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    auto cp = [&](void *host, void *dev, size_t bytes) {
+        return to_device ? hipMemcpyAsync(dev, host, bytes, kind, ctx->stream)
+                         : hipMemcpyAsync(host, dev, bytes, kind, ctx->stream);
+    };
+    if (values) SOTS_HIP(ctx, cp(values, ctx->val(half), pd_bytes));
+    if (steps) SOTS_HIP(ctx, cp(steps, ctx->stp(half), pd_bytes));
+    if (fitness) SOTS_HIP(ctx, cp(fitness, ctx->fit(half), f_bytes));
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SOTS_OK;
+}
+
+int sots_write_population(sots_ctx *ctx, const float *values, size_t values_bytes, const float *steps,
+                          size_t steps_bytes, const float *fitness, size_t fitness_bytes)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    return copy_population(ctx, ctx->rot, true, (void *)values, values_bytes, (void *)steps, steps_bytes,
+                           (void *)fitness, fitness_bytes);
+}
+
+int sots_read_population(sots_ctx *ctx, float *values, size_t values_bytes, float *steps, size_t steps_bytes,
+                         float *fitness, size_t fitness_bytes)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    return copy_population(ctx, ctx->rot, false, values, values_bytes, steps, steps_bytes, fitness, fitness_bytes);
+}
+
+int sots_read_population_other(sots_ctx *ctx, float *values, size_t values_bytes, float *steps,
+                               size_t steps_bytes, float *fitness, size_t fitness_bytes)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    return copy_population(ctx, ctx->rot ^ 1u, false, values, values_bytes, steps, steps_bytes, fitness, fitness_bytes);
+}
+
+// ---- synthesiser buffers ---------------------------------------------------------------
+int sots_write_synth(sots_ctx *ctx, const float *audio, size_t audio_bytes, const float *spectrum,
+                     size_t spectrum_bytes)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    const size_t a_bytes = (size_t)ctx->P * ctx->N * sizeof(float), s_bytes = (size_t)ctx->P * (ctx->N + 8) * sizeof(float);
+    if ((audio && audio_bytes != a_bytes) || (spectrum && spectrum_bytes != s_bytes))
+        return fail(ctx, SOTS_ERR_SIZE, "synth byte counts must be %zu (audio) and %zu (spectrum)", a_bytes, s_bytes);
+    if (int rc = bind_device(ctx)) return rc;
+    if (audio) SOTS_HIP(ctx, hipMemcpyAsync(ctx->audio, audio, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (spectrum) SOTS_HIP(ctx, hipMemcpyAsync(ctx->spectrum, spectrum, s_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SOTS_OK;
+}
+
+int sots_read_synth(sots_ctx *ctx, float *audio, size_t audio_bytes, float *spectrum, size_t spectrum_bytes,
+                    float *target, size_t target_bytes)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    const size_t a_bytes = (size_t)ctx->P * ctx->N * sizeof(float), s_bytes = (size_t)ctx->P * (ctx->N + 8) * sizeof(float);
+    const size_t t_bytes = (size_t)(ctx->N / 2) * sizeof(float);
+    if ((audio && audio_bytes != a_bytes) || (spectrum && spectrum_bytes != s_bytes) || (target && target_bytes != t_bytes))
+        return fail(ctx, SOTS_ERR_SIZE, "synth byte counts must be %zu (audio), %zu (spectrum), %zu (target)",
+                    a_bytes, s_bytes, t_bytes);
+    if (int rc = bind_device(ctx)) return rc;
+    if (audio) SOTS_HIP(ctx, hipMemcpyAsync(audio, ctx->audio, a_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (spectrum) SOTS_HIP(ctx, hipMemcpyAsync(spectrum, ctx->spectrum, s_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (target) SOTS_HIP(ctx, hipMemcpyAsync(target, ctx->target, t_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SOTS_OK;
+}
+
+// ---- stages -------------------------------------------------------------------------------
+int sots_stage_recombine(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
+    {
+        StageScope t(ctx, SOTS_STAGE_RECOMBINE);
+        SOTS_HIP(ctx, launch_recombine(ctx->stream, ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst), ctx->pd));
+    }
+    ctx->rot = dst; // out-of-place recombination: the recombined population is the current one
+    return maybe_drain(ctx);
+}
+
+int sots_stage_mutate(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    {
+        StageScope t(ctx, SOTS_STAGE_MUTATE);
+        SOTS_HIP(ctx, launch_mutate(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->pd, ctx->mc, ctx->generation));
+    }
+    return maybe_drain(ctx);
+}
+
+int sots_stage_synthesise(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    {
+        StageScope t(ctx, SOTS_STAGE_SYNTHESISE);
+        SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, nullptr,
+                                   ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->num_cus));
+    }
+    return maybe_drain(ctx);
+}
+
+int sots_stage_window(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    {
+        StageScope t(ctx, SOTS_STAGE_WINDOW);
+        SOTS_HIP(ctx, launch_window(ctx->stream, ctx->audio, ctx->window, ctx->P, ctx->log2n));
+    }
+    return maybe_drain(ctx);
+}
+
+int sots_stage_fft(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    {
+        StageScope t(ctx, SOTS_STAGE_FFT);
+        SOTS_HIP(ctx, launch_fft(ctx->stream, ctx->audio, ctx->spectrum, ctx->twiddle, ctx->P, ctx->log2n, ctx->num_cus));
+    }
+    return maybe_drain(ctx);
+}
+
+int sots_stage_fitness(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = require_target(ctx)) return rc;
+    if (int rc = bind_device(ctx)) return rc;
+    {
+        StageScope t(ctx, SOTS_STAGE_FITNESS);
+        SOTS_HIP(ctx, launch_fitness(ctx->stream, ctx->spectrum, ctx->target, ctx->fit(ctx->rot), ctx->P, ctx->log2n,
+                                     ctx->inv_n, ctx->inv_wf, ctx->num_cus));
+    }
+    return maybe_drain(ctx);
+}
+
+int sots_stage_sort(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
+    {
+        StageScope t(ctx, SOTS_STAGE_SORT);
+        SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
+                                  ctx->fit(dst), ctx->keys, ctx->P, ctx->D));
+    }
+    return maybe_drain(ctx);
+}
+
+int sots_stage_rotate(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    // rotationIndex_ flip, ...OpenCL.hpp:486; a kernel argument here, so no transfer
+    StageScope t(ctx, SOTS_STAGE_ROTATE);
+    ctx->rot ^= 1u;
+    ctx->generation += 1;
+    return SOTS_OK;
+}
+
+int sots_execute_generation(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = require_target(ctx)) return rc;
+    int rc;
+    if ((rc = sots_stage_recombine(ctx))) return rc;
+    if ((rc = sots_stage_mutate(ctx))) return rc;
+    if ((rc = sots_stage_synthesise(ctx))) return rc;
+    if ((rc = sots_stage_window(ctx))) return rc;
+    if ((rc = sots_stage_fft(ctx))) return rc;
+    if ((rc = sots_stage_fitness(ctx))) return rc;
+    if ((rc = sots_stage_sort(ctx))) return rc;
+    return sots_stage_rotate(ctx);
+}
+
+int sots_execute_generations(sots_ctx *ctx, uint32_t n)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = require_target(ctx)) return rc;
+    if (int rc = bind_device(ctx)) return rc;
+    for (uint32_t g = 0; g < n; ++g) {
+        uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
+        {
+            StageScope t(ctx, SOTS_STAGE_FUSED_VARIATION);
+            SOTS_HIP(ctx, launch_recombine_mutate(ctx->stream, ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst),
+                                                  ctx->pd, ctx->mc, ctx->generation));
+        }
+        ctx->rot = dst;
+        {
+            StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH);
+            SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, ctx->window,
+                                       ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->num_cus));
+        }
+        {
+            StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL);
+            SOTS_HIP(ctx, launch_fft_fitness(ctx->stream, ctx->audio, ctx->target, ctx->fit(ctx->rot), ctx->twiddle, ctx->P,
+                                             ctx->log2n, ctx->inv_n, ctx->inv_wf, ctx->num_cus));
+        }
+        src = ctx->rot;
+        dst = ctx->rot ^ 1u;
+        {
+            StageScope t(ctx, SOTS_STAGE_SORT);
+            SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
+                                      ctx->fit(dst), ctx->keys, ctx->P, ctx->D));
+        }
+        ctx->rot = dst;
+        ctx->generation += 1;
+        if (int rc = maybe_drain(ctx)) return rc;
+    }
+    return SOTS_OK;
+}
+
+int sots_get_generation(const sots_ctx *ctx, uint32_t *generation)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!generation) return fail(ctx, SOTS_ERR_INVALID, "null generation pointer");
+    *generation = ctx->generation;
+    return SOTS_OK;
+}
+
+int sots_set_generation(sots_ctx *ctx, uint32_t generation)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    ctx->generation = generation;
+    return SOTS_OK;
+}
+
+// ---- timing ----------------------------------------------------------------------------------
+int sots_timing_enable(sots_ctx *ctx, int enabled)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    ctx->timing = enabled != 0;
+    return SOTS_OK;
+}
+
+int sots_timing_reset(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
+    for (auto &ck : ctx->clocks) {
+        if (int rc = drain_clock(ctx, ck)) return rc;
+        ck.total_ms = 0.0;
+        ck.count = 0;
+    }
+    return SOTS_OK;
+}
+
+int sots_stage_time_ms(sots_ctx *ctx, int stage, double *total_ms, uint64_t *count)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (stage < 0 || stage >= SOTS_STAGE_COUNT) return fail(ctx, SOTS_ERR_INVALID, "stage %d out of range", stage);
+    if (int rc = bind_device(ctx)) return rc;
+    if (int rc = drain_clock(ctx, ctx->clocks[stage])) return rc;
+    if (total_ms) *total_ms = ctx->clocks[stage].total_ms;
+    if (count) *count = ctx->clocks[stage].count;
+    return SOTS_OK;
+}
+
+// ---- island exchange ------------------------------------------------------------------------
+int sots_pack_elites_device(sots_ctx *ctx, void *device_rows, uint32_t n_rows)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!device_rows || n_rows > ctx->P) return fail(ctx, SOTS_ERR_INVALID, "pack_elites: bad rows/n_rows %u", n_rows);
+    if (int rc = bind_device(ctx)) return rc;
+    SOTS_HIP(ctx, launch_pack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
+                                   (float *)device_rows, 0, n_rows, ctx->D));
+    return SOTS_OK;
+}
+
+int sots_inject_immigrants_device(sots_ctx *ctx, const void *device_rows, uint32_t n_rows)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!device_rows || n_rows > ctx->cfg.num_parents)
+        return fail(ctx, SOTS_ERR_INVALID, "inject_immigrants: %u rows do not fit %u parents", n_rows, ctx->cfg.num_parents);
+    if (int rc = bind_device(ctx)) return rc;
+    SOTS_HIP(ctx, launch_unpack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
+                                     (const float *)device_rows, ctx->cfg.num_parents - n_rows, n_rows, ctx->D));
+    return SOTS_OK;
+}
+
+int sots_pack_elites_host(sots_ctx *ctx, float *rows, uint32_t n_rows)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!rows) return fail(ctx, SOTS_ERR_INVALID, "pack_elites: null rows");
+    if (int rc = bind_device(ctx)) return rc;
+    if (int rc = ensure_rows(ctx, n_rows)) return rc;
+    if (int rc = sots_pack_elites_device(ctx, ctx->rows, n_rows)) return rc;
+    SOTS_HIP(ctx, hipMemcpyAsync(rows, ctx->rows, (size_t)n_rows * (2 * ctx->D + 1) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SOTS_OK;
+}
+
+int sots_inject_immigrants_host(sots_ctx *ctx, const float *rows, uint32_t n_rows)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!rows) return fail(ctx, SOTS_ERR_INVALID, "inject_immigrants: null rows");
+    if (int rc = bind_device(ctx)) return rc;
+    if (int rc = ensure_rows(ctx, n_rows)) return rc;
+    SOTS_HIP(ctx, hipMemcpyAsync(ctx->rows, rows, (size_t)n_rows * (2 * ctx->D + 1) * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = sots_inject_immigrants_device(ctx, ctx->rows, n_rows)) return rc;
+    SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SOTS_OK;
+}
+
+int sots_get_info(const sots_ctx *ctx, sots_info *info)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!info) return fail(ctx, SOTS_ERR_INVALID, "null info");
+    memset(info, 0, sizeof *info);
+    info->population_length = ctx->P;
+    info->num_dimensions = ctx->D;
+    info->audio_length = ctx->N;
+    info->spectrum_row_floats = ctx->N + 8;
+    info->rotation_index = ctx->rot;
+    info->generation = ctx->generation;
+    info->compute_units = ctx->num_cus;
+    snprintf(info->device_name, sizeof info->device_name, "%s", ctx->device_name);
+    snprintf(info->arch, sizeof info->arch, "%s", ctx->arch);
+    return SOTS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,80 @@
+// sots_kernels.h -- host-callable launchers of the gfx950 kernels (sots_kernels.hip).
+// Internal to libsots_hip.so; the public boundary is include/sots_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/sots_hip.h"
+
+namespace sots {
+
+constexpr uint32_t kWavetableSize = SOTS_WAVETABLE_SIZE;
+constexpr uint32_t kTagInit = 0x494e4954u;   // PRNG domain words (4th Philox counter word)
+constexpr uint32_t kTagMutate = 0x4d555441u;
+
+// ES constants, Evolutionary_Strategy.hpp:611-627; the two pow(Ek, beta) values are
+// evaluated once on the host (Ek only ever takes two values, ocl_program.cl:168,185).
+struct MutateConsts {
+    float alpha, one_over_alpha, root_two_over_pi, beta_scale;
+    float pow_alpha_beta, pow_inv_alpha_beta;
+};
+
+struct SynthParams {
+    float pmin[SOTS_MAX_DIMS];
+    float pmax[SOTS_MAX_DIMS];
+};
+
+// Population geometry shared by most launches.
+struct PopDims {
+    uint32_t p;            // populationLength
+    uint32_t d;            // numDimensions
+    uint32_t num_parents;
+    uint32_t block;        // recombination block (reference WRKGRPSIZE)
+    uint32_t gid_base;
+    uint32_t seed_lo, seed_hi;
+};
+
+// ---- variation ----
+hipError_t launch_init_population(hipStream_t st, float *values, float *steps, float *fitness,
+                                  const PopDims &pd, uint32_t chunk);
+hipError_t launch_recombine(hipStream_t st, const float *vin, const float *sin, float *vout, float *sout,
+                            const PopDims &pd);
+hipError_t launch_mutate(hipStream_t st, float *values, float *steps, const PopDims &pd,
+                         const MutateConsts &mc, uint32_t generation);
+// recombine (in -> out) and mutate fused
+hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float *sin, float *vout,
+                                   float *sout, const PopDims &pd, const MutateConsts &mc,
+                                   uint32_t generation);
+
+// ---- evaluation ----
+// window == nullptr: raw synthesis; else audio is multiplied by the fp32 window on the way out
+hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
+                        const float *window, float *audio, const SynthParams &sp, uint32_t p,
+                        uint32_t log2n, uint32_t num_cus);
+hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n);
+// audio[P][N] -> spectrum[P][N+8]
+hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
+                      uint32_t p, uint32_t log2n, uint32_t num_cus);
+// spectrum[P][N+8] x target[N/2] -> fitness[P]
+hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
+                          uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus);
+// audio[P][N] x target -> fitness[P] without materialising the spectrum
+hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *target, float *fitness,
+                              const float2 *twiddle, uint32_t p, uint32_t log2n, float inv_n,
+                              float inv_wf, uint32_t num_cus);
+
+// ---- selection ----
+// keys: P_pad 64-bit words of scratch (P_pad = next power of two >= P)
+hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
+                       float *vout, float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d);
+
+// ---- island exchange ----
+hipError_t launch_pack_rows(hipStream_t st, const float *values, const float *steps, const float *fitness,
+                            float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d);
+hipError_t launch_unpack_rows(hipStream_t st, float *values, float *steps, float *fitness,
+                              const float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d);
+
+uint32_t next_pow2(uint32_t v);
+
+} // namespace sots

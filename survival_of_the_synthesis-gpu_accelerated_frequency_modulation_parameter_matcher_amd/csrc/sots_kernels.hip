@@ -1,0 +1,906 @@
+// sots_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the per-generation
+// evolutionary FM sound-matching loop.  Compiled with -ffp-contract=off: every fp32
+// expression rounds exactly as written, which is what makes synthesis, recombination and
+// the value half of mutation bit-identical to the CPU restatement.
+//
+// Layout choices (DESIGN.md has the reasoning):
+//   * variation kernels        : one lane per gene, coalesced [P][D] rows
+//   * synthesisePopulation     : one lane per individual (the phase recurrence is serial in
+//                                fp32), 128 KiB wavetable staged in LDS, 16-byte row stores
+//   * FFT / fitness            : one individual per wavefront, Stockham radix-8/4 passes
+//                                (three/two radix-2 layers kept in registers), padded LDS
+//                                exchange, xor-shuffle reduction of the squared error
+//   * sortPopulation           : bitonic network on (fitness, index) 64-bit keys, LDS tiles
+//
+// Reference citations are file:line in the reference tree.
+#include "sots_kernels.h"
+
+namespace sots {
+
+uint32_t next_pow2(uint32_t v)
+{
+    uint32_t r = 1;
+    while (r < v) r <<= 1;
+    return r;
+}
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011).  Replaces MWC64X (ocl_program.cl:5-16): the state
+// is the counter (global individual id, epoch, block, domain) under the key (seed).
+// ------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ uint32_t u4_at(const U4 &v, uint32_t i)
+{
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// (float)((int)MWC64X) / 2147483647.0f, ocl_program.cl:27,61
+__device__ __forceinline__ float draw_unit(uint32_t w)
+{
+    return (float)((int32_t)w) / 2147483647.0f;
+}
+
+// ------------------------------------------------------------------------------------
+// initPopulation, ocl_program.cl:46-66
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_population(float *__restrict__ values,
+                                                         float *__restrict__ steps,
+                                                         float *__restrict__ fitness, PopDims pd,
+                                                         uint32_t chunk)
+{
+    const uint32_t total = pd.p * pd.d;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t i = e / pd.d, g = e - i * pd.d;
+        const U4 r = philox4x32_10(pd.gid_base + i, chunk, g >> 2, kTagInit, pd.seed_lo, pd.seed_hi);
+        const float u = draw_unit(u4_at(r, g & 3u));
+        steps[e] = 0.1f;
+        values[e] = (u < 0.0f) ? -u : u;
+        if (g == 0) fitness[i] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// recombinePopulation, ocl_program.cl:73-149.  Block b copies parent block b % NPB and
+// moves gene g of local individual l to local individual (l + g*(b+1)) mod B (:130-137).
+// Out of place (current half -> other half): the reference's in-place version lets
+// offspring blocks read parent rows that parent blocks are overwriting (:104-147).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t recombine_source(uint32_t i, uint32_t g, const PopDims &pd)
+{
+    const uint32_t b = i / pd.block, dl = i - b * pd.block;
+    uint32_t npb = pd.num_parents / pd.block;
+    npb = npb ? npb : 1u;
+    const uint32_t pb = b % npb;
+    const uint32_t shift = (uint32_t)(((uint64_t)g * (b + 1u)) % pd.block);
+    const uint32_t l = (dl + pd.block - shift) % pd.block;
+    return (pb * pd.block + l) * pd.d + g;
+}
+
+__global__ __launch_bounds__(256) void k_recombine(const float *__restrict__ vin,
+                                                   const float *__restrict__ sin,
+                                                   float *__restrict__ vout,
+                                                   float *__restrict__ sout, PopDims pd)
+{
+    const uint32_t total = pd.p * pd.d;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t i = e / pd.d, g = e - i * pd.d;
+        const uint32_t src = recombine_source(i, g, pd);
+        vout[e] = vin[src];
+        sout[e] = sin[src];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// mutatePopulation, ocl_program.cl:155-190.  13 draws per gene = Philox blocks 4g..4g+3.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void mutate_gene(float &x, float &s, uint32_t gid, uint32_t g,
+                                            uint32_t generation, const PopDims &pd,
+                                            const MutateConsts &mc)
+{
+    const U4 r0 = philox4x32_10(gid, generation, 4u * g + 0u, kTagMutate, pd.seed_lo, pd.seed_hi);
+    const U4 r1 = philox4x32_10(gid, generation, 4u * g + 1u, kTagMutate, pd.seed_lo, pd.seed_hi);
+    const U4 r2 = philox4x32_10(gid, generation, 4u * g + 2u, kTagMutate, pd.seed_lo, pd.seed_hi);
+    const U4 r3 = philox4x32_10(gid, generation, 4u * g + 3u, kTagMutate, pd.seed_lo, pd.seed_hi);
+    const bool even = (r0.x % 2u) == 0u;
+    const float ek = even ? mc.alpha : mc.one_over_alpha;             // :168
+    const float pw = even ? mc.pow_alpha_beta : mc.pow_inv_alpha_beta; // pow(Ek, BETA), :185
+    float sum = 0.0f;                                                  // gauss_rand, :21-31
+    sum += draw_unit(r0.y); sum += draw_unit(r0.z); sum += draw_unit(r0.w);
+    sum += draw_unit(r1.x); sum += draw_unit(r1.y); sum += draw_unit(r1.z); sum += draw_unit(r1.w);
+    sum += draw_unit(r2.x); sum += draw_unit(r2.y); sum += draw_unit(r2.z); sum += draw_unit(r2.w);
+    sum += draw_unit(r3.x);
+    sum /= 12.0f;
+    float gauss = sum;
+    float new_x = x + ek * s * gauss;                                  // :174
+    if (new_x < 0.0f || new_x > 1.0f) {                                // :176-182
+        gauss = gauss * -0.5f;
+        new_x = x + ek * s * gauss;
+    }
+    const float es = expf(fabsf(gauss) - mc.root_two_over_pi);         // :184
+    s *= pw * powf(es, mc.beta_scale);                                 // :185
+    x = new_x;
+}
+
+__global__ __launch_bounds__(256) void k_mutate(float *__restrict__ values, float *__restrict__ steps,
+                                                PopDims pd, MutateConsts mc, uint32_t generation)
+{
+    const uint32_t total = pd.p * pd.d;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t i = e / pd.d, g = e - i * pd.d;
+        float x = values[e], s = steps[e];
+        mutate_gene(x, s, pd.gid_base + i, g, generation, pd, mc);
+        values[e] = x;
+        steps[e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_recombine_mutate(const float *__restrict__ vin,
+                                                          const float *__restrict__ sin,
+                                                          float *__restrict__ vout,
+                                                          float *__restrict__ sout, PopDims pd,
+                                                          MutateConsts mc, uint32_t generation)
+{
+    const uint32_t total = pd.p * pd.d;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t i = e / pd.d, g = e - i * pd.d;
+        const uint32_t src = recombine_source(i, g, pd);
+        float x = vin[src], s = sin[src];
+        mutate_gene(x, s, pd.gid_base + i, g, generation, pd, mc);
+        vout[e] = x;
+        sout[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// synthesisePopulation{,DoubleSeries,TripleParallel}, ocl_program.cl:280-443 /
+// Objective::synthesiseAudio*, Evolutionary_Strategy.hpp:368-495.
+//
+// The oscillator phases are fp32 running sums with a conditional wrap per sample, so a
+// voice is serial in the sample index: one lane owns one individual.  The 32768-entry
+// wavetable (128 KiB) lives in LDS, one workgroup per CU; the phase chains of UNROLL
+// samples run ahead of the table reads that hang off them so that the LDS latency of a
+// gather is not on the recurrence.  Each lane stores 16 bytes at a time into its own
+// audio row.
+// ------------------------------------------------------------------------------------
+constexpr int kSynthThreads = 256;
+constexpr int kSynthUnroll = 8;
+constexpr float kWf = (float)kWavetableSize;
+
+__device__ __forceinline__ float tab_at(const float *tab, float pos)
+{
+    int i = (int)pos; // == (unsigned)pos for every in-range phase
+    i = min(max(i, 0), (int)kWavetableSize - 1);
+    return tab[i];
+}
+__device__ __forceinline__ void wrap_hi(float &p) { if (p >= kWf) p -= kWf; }
+__device__ __forceinline__ void wrap_lo(float &p) { if (p < 0.0f) p += kWf; }
+
+template <bool WINDOW>
+__device__ __forceinline__ void store_block(float *__restrict__ out, const float (&y)[kSynthUnroll],
+                                            const float *__restrict__ window, uint32_t i)
+{
+    float v[kSynthUnroll];
+#pragma unroll
+    for (int u = 0; u < kSynthUnroll; ++u) v[u] = WINDOW ? y[u] * window[i + u] : y[u];
+#pragma unroll
+    for (int u = 0; u < kSynthUnroll; u += 4)
+        *reinterpret_cast<float4 *>(out + i + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+}
+
+template <int KIND, bool WINDOW>
+__global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict__ values,
+                                                         const float *__restrict__ wavetable,
+                                                         const float *__restrict__ window,
+                                                         float *__restrict__ audio, SynthParams sp,
+                                                         uint32_t p_len, uint32_t n)
+{
+    __shared__ float tab[kWavetableSize];
+    for (uint32_t i = threadIdx.x * 4u; i < kWavetableSize; i += kSynthThreads * 4u)
+        *reinterpret_cast<float4 *>(&tab[i]) = *reinterpret_cast<const float4 *>(&wavetable[i]);
+    __syncthreads();
+
+    constexpr int D = KIND == SOTS_SYNTH_2OP ? 4 : KIND == SOTS_SYNTH_3OP_SERIES ? 6
+                    : KIND == SOTS_SYNTH_TRIPLE_PAR ? 12 : 8;
+    // w2srRatio, Evolutionary_Strategy.hpp:203
+    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
+
+    for (uint32_t base = blockIdx.x * kSynthThreads; base < p_len; base += gridDim.x * kSynthThreads) {
+        const uint32_t ind = base + threadIdx.x;
+        if (ind >= p_len) continue;
+        float p[D];
+#pragma unroll
+        for (int g = 0; g < D; ++g) {
+            // scaleParams: min + v*(max-min), ocl_program.cl:297; the triple voice scales all
+            // three 2-op voices by entries 0..3, Evolutionary_Strategy.hpp:453-455
+            const int s = KIND == SOTS_SYNTH_TRIPLE_PAR ? (g & 3) : g;
+            p[g] = sp.pmin[s] + values[(size_t)ind * D + g] * (sp.pmax[s] - sp.pmin[s]);
+        }
+        float *__restrict__ out = audio + (size_t)ind * n;
+
+        if constexpr (KIND == SOTS_SYNTH_2OP) {
+            // Evolutionary_Strategy.hpp:372-401
+            const float mod = p[0] * p[1], fc = p[2], amp = p[3];
+            const float inc1 = c * p[0];
+            float pos1 = 0.0f, pos2 = 0.0f;
+            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
+                float t1[kSynthUnroll], y[kSynthUnroll];
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u) {
+                    t1[u] = tab_at(tab, pos1);
+                    pos1 += inc1;
+                    wrap_hi(pos1);
+                }
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u) {
+                    const float cur = t1[u] * mod + fc;
+                    y[u] = tab_at(tab, pos2);
+                    pos2 += c * cur;
+                    wrap_hi(pos2);
+                    wrap_lo(pos2);
+                }
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u) y[u] = y[u] * amp;
+                store_block<WINDOW>(out, y, window, i);
+            }
+        } else if constexpr (KIND == SOTS_SYNTH_3OP_SERIES || KIND == SOTS_SYNTH_4OP_SERIES) {
+            // Evolutionary_Strategy.hpp:407-445; the 4-op voice adds one more modulator stage
+            constexpr int OPS = KIND == SOTS_SYNTH_3OP_SERIES ? 3 : 4;
+            float m[OPS];
+#pragma unroll
+            for (int o = 0; o < OPS; ++o) m[o] = p[2 * o] * p[2 * o + 1];
+            const float inc1 = c * p[1];
+            float pos[OPS];
+#pragma unroll
+            for (int o = 0; o < OPS; ++o) pos[o] = 0.0f;
+            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
+                float t[kSynthUnroll], y[kSynthUnroll];
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u) {
+                    t[u] = tab_at(tab, pos[0]);
+                    pos[0] += inc1;
+                    wrap_hi(pos[0]);
+                }
+#pragma unroll
+                for (int o = 1; o < OPS; ++o) {
+                    // offset of modulator o-1 is params[2(o-1)+3] (:420,427)
+                    const float mm = m[o - 1], off = p[2 * (o - 1) + 3];
+#pragma unroll
+                    for (int u = 0; u < kSynthUnroll; ++u) {
+                        const float cur = t[u] * mm + off;
+                        t[u] = tab_at(tab, pos[o]);
+                        pos[o] += c * cur;
+                        wrap_hi(pos[o]);
+                        wrap_lo(pos[o]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u) y[u] = t[u] * m[OPS - 1];
+                store_block<WINDOW>(out, y, window, i);
+            }
+        } else {
+            // Evolutionary_Strategy.hpp:457-494
+            float mod[3], fc[3], amp[3], inc[3], pa[3], pb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                mod[j] = p[4 * j] * p[4 * j + 1];
+                fc[j] = p[4 * j + 2];
+                amp[j] = p[4 * j + 3];
+                inc[j] = c * p[4 * j];
+                pa[j] = 0.0f;
+                pb[j] = 0.0f;
+            }
+            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
+                float tot[3][kSynthUnroll], y[kSynthUnroll];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float t1[kSynthUnroll];
+#pragma unroll
+                    for (int u = 0; u < kSynthUnroll; ++u) {
+                        t1[u] = tab_at(tab, pa[j]);
+                        pa[j] += inc[j];
+                        wrap_hi(pa[j]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kSynthUnroll; ++u) {
+                        const float cur = t1[u] * mod[j] + fc[j];
+                        tot[j][u] = tab_at(tab, pb[j]) * amp[j];
+                        pb[j] += c * cur;
+                        wrap_hi(pb[j]);
+                        wrap_lo(pb[j]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u)
+                    y[u] = (tot[0][u] + tot[1][u] + tot[2][u]) / 3.0f; // == (float)(double(sum)/3.0), :493
+                store_block<WINDOW>(out, y, window, i);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// applyWindowPopulation, ocl_program.cl:566-586.  The table is the reference's double
+// window (Evolutionary_Strategy.hpp:308-317) rounded once to fp32.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window(float *__restrict__ audio, const float *__restrict__ window,
+                                                size_t total4, uint32_t n_mask4)
+{
+    float4 *a4 = reinterpret_cast<float4 *>(audio);
+    const float4 *w4 = reinterpret_cast<const float4 *>(window);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
+         e += (size_t)gridDim.x * blockDim.x) {
+        float4 v = a4[e];
+        const float4 w = w4[e & n_mask4];
+        v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+        a4[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Batched real FFT (replaces clFFT, Evolutionary_Strategy_OpenCL.hpp:156-192,555-561)
+// and fitnessPopulation (ocl_program.cl:594-659 with the CPU bin range k < N/2,
+// Evolutionary_Strategy_CPU.hpp:235).
+//
+// One wavefront transforms one individual: the N real samples are read as M = N/2 complex
+// points, E = M/64 per lane, and go through Stockham autosort passes of radix 8 or 4 (three
+// or two radix-2 butterfly layers done in registers), exchanging through a padded LDS
+// buffer between passes.  A final split step turns Z[k], Z[M-k] into the real-input bins
+// X[k], X[M-k].
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); } // a * (-i)
+
+template <int R> struct Dft;
+template <> struct Dft<2> {
+    static __device__ __forceinline__ void run(float2 *v)
+    {
+        const float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+template <> struct Dft<4> {
+    static __device__ __forceinline__ void run(float2 *v)
+    {
+        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        const float2 t2 = cadd(v[1], v[3]), t3 = mul_neg_i(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2);
+        v[1] = cadd(t1, t3);
+        v[2] = csub(t0, t2);
+        v[3] = csub(t1, t3);
+    }
+};
+template <> struct Dft<8> {
+    static __device__ __forceinline__ void run(float2 *v)
+    {
+        float2 e[4] = {v[0], v[2], v[4], v[6]};
+        float2 o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<4>::run(e);
+        Dft<4>::run(o);
+        const float s = 0.70710678118654752440f;
+        // o[k] *= exp(-2 pi i k / 8)
+        o[1] = make_float2((o[1].x + o[1].y) * s, (o[1].y - o[1].x) * s);
+        o[2] = mul_neg_i(o[2]);
+        o[3] = make_float2((o[3].y - o[3].x) * s, -(o[3].x + o[3].y) * s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = cadd(e[k], o[k]);
+            v[k + 4] = csub(e[k], o[k]);
+        }
+    }
+};
+
+// LDS index padding: one extra complex slot per 8 keeps the stride-8 / stride-64 writes of
+// the first two passes and the unit-stride reads off each other's banks.
+__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 3); }
+
+// One Stockham pass of radix R with NS = product of the radices already applied.
+// Register slot s holds element lane + 64 s of the pass input; butterfly b uses slots
+// b + t*(E/R), t < R.  Output element t of butterfly j goes to (j-k)*R + k + t*NS with
+// k = j mod NS.
+template <int M, int R, int NS>
+__device__ __forceinline__ void fft_pass(float2 (&x)[M / kWave], float2 *__restrict__ lds,
+                                         const float2 *__restrict__ tw, int lane)
+{
+    constexpr int E = M / kWave, B = E / R;
+    static_assert(E % R == 0, "radix must divide the per-lane element count");
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int j = lane + kWave * b;
+        const int k = j & (NS - 1);
+        float2 v[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) v[t] = x[b + t * B];
+        if constexpr (NS > 1) {
+            // twiddle e^{-2 pi i t k / (NS R)} from the N-entry table e^{-2 pi i q / N}, N = 2M
+            constexpr int stride = (2 * M) / (NS * R);
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], tw[t * k * stride]);
+        }
+        Dft<R>::run(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int t = 0; t < R; ++t) lds[lds_pad(j0 + t * NS)] = v[t];
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void lds_reload(float2 (&x)[M / kWave], const float2 *__restrict__ lds, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < M / kWave; ++s) x[s] = lds[lds_pad(lane + kWave * s)];
+}
+
+// All passes for M complex points; leaves Z in natural order in LDS (padded indexing).
+template <int M>
+__device__ __forceinline__ void fft_forward(float2 (&x)[M / kWave], float2 *__restrict__ lds,
+                                            const float2 *__restrict__ tw, int lane)
+{
+#define SOTS_PASS(R, NS)                     \
+    fft_pass<M, R, NS>(x, lds, tw, lane);    \
+    __syncthreads();
+#define SOTS_NEXT()                          \
+    lds_reload<M>(x, lds, lane);             \
+    __syncthreads();
+    if constexpr (M == 256) {
+        SOTS_PASS(4, 1) SOTS_NEXT() SOTS_PASS(4, 4) SOTS_NEXT() SOTS_PASS(4, 16) SOTS_NEXT() SOTS_PASS(4, 64)
+    } else if constexpr (M == 512) {
+        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64)
+    } else if constexpr (M == 1024) {
+        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(4, 64) SOTS_NEXT() SOTS_PASS(4, 256)
+    } else if constexpr (M == 2048) {
+        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(4, 512)
+    } else {
+        static_assert(M == 4096, "unsupported FFT length");
+        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(8, 512)
+    }
+#undef SOTS_PASS
+#undef SOTS_NEXT
+}
+
+// Real-input split for the pair (k, M-k), 0 < k < M/2:
+//   Ee = (Z[k] + conj Z[M-k]) / 2,  Oo = -i (Z[k] - conj Z[M-k]) / 2,  T = e^{-2 pi i k/N} Oo
+//   X[k] = Ee + T,  X[M-k] = conj(Ee - T)
+// k == 0 pairs bin 0 with bin M/2 instead: X[0] = Re Z0 + Im Z0, X[M/2] = conj Z[M/2];
+// the Nyquist bin X[M] = Re Z0 - Im Z0 is returned separately.
+template <int M>
+__device__ __forceinline__ void split_pair(const float2 *__restrict__ lds, const float2 *__restrict__ tw,
+                                           int k, float2 &xa, float2 &xb, float2 &nyq)
+{
+    if (k == 0) {
+        const float2 z0 = lds[lds_pad(0)], zh = lds[lds_pad(M / 2)];
+        xa = make_float2(z0.x + z0.y, 0.0f);
+        xb = make_float2(zh.x, -zh.y);
+        nyq = make_float2(z0.x - z0.y, 0.0f);
+    } else {
+        const float2 a = lds[lds_pad(k)], bz = lds[lds_pad(M - k)];
+        const float2 b = make_float2(bz.x, -bz.y);
+        const float2 ee = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+        const float2 dd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+        const float2 oo = make_float2(dd.y, -dd.x);
+        const float2 t = cmul(oo, tw[k]);
+        xa = cadd(ee, t);
+        const float2 d2 = csub(ee, t);
+        xb = make_float2(d2.x, -d2.y);
+    }
+}
+
+// |X| / N / windowFactor, Evolutionary_Strategy.hpp:517-519 / ocl_program.cl:608-611
+__device__ __forceinline__ float bin_error(float2 x, float target, float inv_n, float inv_wf)
+{
+    const float raw = sqrtf(x.x * x.x + x.y * x.y);
+    const float mag = raw * inv_n * inv_wf;
+    const float e = mag - target;
+    return e * e;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// MODE 0: write spectrum rows; MODE 1: accumulate the fitness directly
+template <int LOG2N, int MODE>
+__global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
+                                               const float *__restrict__ target, float *__restrict__ fitness,
+                                               const float2 *__restrict__ tw, uint32_t p_len, float inv_n,
+                                               float inv_wf)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave;
+    __shared__ float2 lds[M + M / 8 + 1];
+    const int lane = threadIdx.x;
+    for (uint32_t ind = blockIdx.x; ind < p_len; ind += gridDim.x) {
+        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * N);
+        float2 x[E];
+#pragma unroll
+        for (int s = 0; s < E; ++s) x[s] = in[lane + kWave * s];
+        fft_forward<M>(x, lds, tw, lane);
+        if constexpr (MODE == 0) {
+            float2 *__restrict__ row = reinterpret_cast<float2 *>(spectrum + (size_t)ind * (N + 8));
+#pragma unroll
+            for (int q = 0; q < E / 2; ++q) {
+                const int k = lane + kWave * q;
+                float2 xa, xb, nyq;
+                split_pair<M>(lds, tw, k, xa, xb, nyq);
+                row[k] = xa;
+                row[k == 0 ? M / 2 : M - k] = xb;
+                if (k == 0) row[M] = nyq;
+            }
+        } else {
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < E / 2; ++q) {
+                const int k = lane + kWave * q;
+                float2 xa, xb, nyq;
+                split_pair<M>(lds, tw, k, xa, xb, nyq);
+                const int kb = k == 0 ? M / 2 : M - k;
+                acc += bin_error(xa, target[k], inv_n, inv_wf);
+                acc += bin_error(xb, target[kb], inv_n, inv_wf);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) fitness[ind] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// fitnessPopulation on materialised spectrum rows; same bin -> lane assignment and
+// summation order as k_fft<.., 1>, so both paths give the same fp32 sum.
+template <int LOG2N>
+__global__ __launch_bounds__(kWave) void k_fitness(const float *__restrict__ spectrum,
+                                                   const float *__restrict__ target,
+                                                   float *__restrict__ fitness, uint32_t p_len, float inv_n,
+                                                   float inv_wf)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave;
+    const int lane = threadIdx.x;
+    for (uint32_t ind = blockIdx.x; ind < p_len; ind += gridDim.x) {
+        const float2 *__restrict__ row = reinterpret_cast<const float2 *>(spectrum + (size_t)ind * (N + 8));
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < E / 2; ++q) {
+            const int k = lane + kWave * q;
+            const int kb = k == 0 ? M / 2 : M - k;
+            acc += bin_error(row[k], target[k], inv_n, inv_wf);
+            acc += bin_error(row[kb], target[kb], inv_n, inv_wf);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) fitness[ind] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// sortPopulation, ocl_program.cl:664-711 (rank sort) / Population::bubbleSortPopulation,
+// Evolutionary_Strategy.hpp:108-124.  Ascending by fitness, equal fitness keeps the lower
+// original index first (the CPU's stable order), NaN after every number.  Implemented as a
+// bitonic network over unique 64-bit keys (order-preserving fitness bits << 32 | index).
+// ------------------------------------------------------------------------------------
+constexpr int kSortThreads = 1024;
+constexpr uint32_t kSortTile = 4096; // keys per LDS tile (32 KiB)
+
+__device__ __forceinline__ uint64_t make_key(float f, uint32_t idx)
+{
+    uint32_t u;
+    if (f != f) {
+        u = 0xFFFFFFFFu;
+    } else {
+        u = __float_as_uint(f == 0.0f ? 0.0f : f);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    return ((uint64_t)u << 32) | idx;
+}
+
+__device__ __forceinline__ void cmp_swap(uint64_t &a, uint64_t &b, bool ascending)
+{
+    if ((a > b) == ascending) {
+        const uint64_t t = a;
+        a = b;
+        b = t;
+    }
+}
+
+// Builds the keys of one tile and sorts it completely (all steps with k <= tile).
+__global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const float *__restrict__ fitness,
+                                                             uint64_t *__restrict__ keys, uint32_t p_len,
+                                                             uint32_t tile)
+{
+    __shared__ uint64_t s[kSortTile];
+    const uint32_t base = blockIdx.x * tile;
+    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) {
+        const uint32_t g = base + i;
+        s[i] = g < p_len ? make_key(fitness[g], g) : ~0ull;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= tile; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < tile / 2; t += kSortThreads) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t hi = lo | j;
+                const bool asc = (((base + lo) & k) == 0);
+                uint64_t a = s[lo], b = s[hi];
+                cmp_swap(a, b, asc);
+                s[lo] = a;
+                s[hi] = b;
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) keys[base + i] = s[i];
+}
+
+// One compare-exchange step (k, j) with j >= tile, over the whole padded array.
+__global__ __launch_bounds__(256) void k_sort_global_step(uint64_t *__restrict__ keys, uint32_t n_pad,
+                                                          uint32_t k, uint32_t j)
+{
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_pad / 2; t += gridDim.x * blockDim.x) {
+        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint32_t hi = lo | j;
+        const bool asc = ((lo & k) == 0);
+        uint64_t a = keys[lo], b = keys[hi];
+        cmp_swap(a, b, asc);
+        keys[lo] = a;
+        keys[hi] = b;
+    }
+}
+
+// The remaining steps j = tile/2 .. 1 of merge size k, tile-local.
+__global__ __launch_bounds__(kSortThreads) void k_sort_tile_merge(uint64_t *__restrict__ keys, uint32_t k,
+                                                                  uint32_t tile)
+{
+    __shared__ uint64_t s[kSortTile];
+    const uint32_t base = blockIdx.x * tile;
+    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) s[i] = keys[base + i];
+    __syncthreads();
+    const bool asc = ((base & k) == 0); // k > tile: the direction is uniform over the tile
+    for (uint32_t j = tile >> 1; j > 0; j >>= 1) {
+        for (uint32_t t = threadIdx.x; t < tile / 2; t += kSortThreads) {
+            const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const uint32_t hi = lo | j;
+            uint64_t a = s[lo], b = s[hi];
+            cmp_swap(a, b, asc);
+            s[lo] = a;
+            s[hi] = b;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) keys[base + i] = s[i];
+}
+
+// Row r of the new half <- row (keys[r] & 0xffffffff) of the old half.
+__global__ __launch_bounds__(256) void k_sort_gather(const uint64_t *__restrict__ keys,
+                                                     const float *__restrict__ vin,
+                                                     const float *__restrict__ sin,
+                                                     const float *__restrict__ fin, float *__restrict__ vout,
+                                                     float *__restrict__ sout, float *__restrict__ fout,
+                                                     uint32_t p_len, uint32_t d)
+{
+    const uint32_t w = 2 * d + 1;
+    const uint32_t total = p_len * w;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t r = e / w, c = e - r * w;
+        const uint32_t src = (uint32_t)keys[r];
+        if (c < d) vout[r * d + c] = vin[src * d + c];
+        else if (c < 2 * d) sout[r * d + (c - d)] = sin[src * d + (c - d)];
+        else fout[r] = fin[src];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// island exchange: rows of [fitness, values, steps]
+// ------------------------------------------------------------------------------------
+__global__ void k_pack_rows(const float *__restrict__ values, const float *__restrict__ steps,
+                            const float *__restrict__ fitness, float *__restrict__ rows,
+                            uint32_t first_row, uint32_t n_rows, uint32_t d)
+{
+    const uint32_t w = 2 * d + 1, total = n_rows * w;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t r = e / w, c = e - r * w, src = first_row + r;
+        rows[e] = c == 0 ? fitness[src] : c <= d ? values[src * d + (c - 1)] : steps[src * d + (c - 1 - d)];
+    }
+}
+
+__global__ void k_unpack_rows(float *__restrict__ values, float *__restrict__ steps,
+                              float *__restrict__ fitness, const float *__restrict__ rows,
+                              uint32_t first_row, uint32_t n_rows, uint32_t d)
+{
+    const uint32_t w = 2 * d + 1, total = n_rows * w;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t r = e / w, c = e - r * w, dst = first_row + r;
+        const float v = rows[e];
+        if (c == 0) fitness[dst] = v;
+        else if (c <= d) values[dst * d + (c - 1)] = v;
+        else steps[dst * d + (c - 1 - d)] = v;
+    }
+}
+
+inline uint32_t grid_for(uint64_t work, uint32_t threads, uint32_t cap = 2048)
+{
+    uint64_t g = (work + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+hipError_t launch_init_population(hipStream_t st, float *values, float *steps, float *fitness,
+                                  const PopDims &pd, uint32_t chunk)
+{
+    k_init_population<<<grid_for((uint64_t)pd.p * pd.d, 256), 256, 0, st>>>(values, steps, fitness, pd, chunk);
+    return hipGetLastError();
+}
+
+hipError_t launch_recombine(hipStream_t st, const float *vin, const float *sin, float *vout, float *sout,
+                            const PopDims &pd)
+{
+    k_recombine<<<grid_for((uint64_t)pd.p * pd.d, 256), 256, 0, st>>>(vin, sin, vout, sout, pd);
+    return hipGetLastError();
+}
+
+hipError_t launch_mutate(hipStream_t st, float *values, float *steps, const PopDims &pd,
+                         const MutateConsts &mc, uint32_t generation)
+{
+    k_mutate<<<grid_for((uint64_t)pd.p * pd.d, 256), 256, 0, st>>>(values, steps, pd, mc, generation);
+    return hipGetLastError();
+}
+
+hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float *sin, float *vout,
+                                   float *sout, const PopDims &pd, const MutateConsts &mc,
+                                   uint32_t generation)
+{
+    k_recombine_mutate<<<grid_for((uint64_t)pd.p * pd.d, 256), 256, 0, st>>>(vin, sin, vout, sout, pd, mc,
+                                                                               generation);
+    return hipGetLastError();
+}
+
+template <int KIND>
+static hipError_t launch_synth_kind(hipStream_t st, const float *values, const float *wavetable,
+                                    const float *window, float *audio, const SynthParams &sp, uint32_t p,
+                                    uint32_t n, uint32_t grid)
+{
+    if (window)
+        k_synth<KIND, true><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n);
+    else
+        k_synth<KIND, false><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
+                        const float *window, float *audio, const SynthParams &sp, uint32_t p,
+                        uint32_t log2n, uint32_t num_cus)
+{
+    const uint32_t n = 1u << log2n;
+    // one 128 KiB-LDS workgroup per CU; further individuals are taken in a block-stride loop
+    const uint32_t grid = grid_for(p, kSynthThreads, num_cus ? num_cus : 256);
+    switch (kind) {
+    case SOTS_SYNTH_2OP: return launch_synth_kind<SOTS_SYNTH_2OP>(st, values, wavetable, window, audio, sp, p, n, grid);
+    case SOTS_SYNTH_3OP_SERIES: return launch_synth_kind<SOTS_SYNTH_3OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, grid);
+    case SOTS_SYNTH_TRIPLE_PAR: return launch_synth_kind<SOTS_SYNTH_TRIPLE_PAR>(st, values, wavetable, window, audio, sp, p, n, grid);
+    case SOTS_SYNTH_4OP_SERIES: return launch_synth_kind<SOTS_SYNTH_4OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, grid);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n)
+{
+    const size_t total4 = ((size_t)p << log2n) / 4;
+    const uint32_t mask4 = ((1u << log2n) / 4) - 1;
+    k_window<<<grid_for(total4, 256, 8192), 256, 0, st>>>(audio, window, total4, mask4);
+    return hipGetLastError();
+}
+
+#define SOTS_DISPATCH_LOG2N(log2n, CALL)  \
+    switch (log2n) {                      \
+    case 9: { CALL(9); break; }           \
+    case 10: { CALL(10); break; }         \
+    case 11: { CALL(11); break; }         \
+    case 12: { CALL(12); break; }         \
+    case 13: { CALL(13); break; }         \
+    default: return hipErrorInvalidValue; \
+    }
+
+static uint32_t wave_grid(uint32_t p, uint32_t num_cus)
+{
+    // one wavefront per individual; enough workgroups to fill every CU several times over
+    const uint32_t cap = (num_cus ? num_cus : 256) * 32;
+    return p < cap ? p : cap;
+}
+
+hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
+                      uint32_t p, uint32_t log2n, uint32_t num_cus)
+{
+    const uint32_t grid = wave_grid(p, num_cus);
+#define CALL(L) k_fft<L, 0><<<grid, kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, p, 0.f, 0.f)
+    SOTS_DISPATCH_LOG2N(log2n, CALL)
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
+                          uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus)
+{
+    const uint32_t grid = wave_grid(p, num_cus);
+#define CALL(L) k_fitness<L><<<grid, kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
+    SOTS_DISPATCH_LOG2N(log2n, CALL)
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *target, float *fitness,
+                              const float2 *twiddle, uint32_t p, uint32_t log2n, float inv_n,
+                              float inv_wf, uint32_t num_cus)
+{
+    const uint32_t grid = wave_grid(p, num_cus);
+#define CALL(L) k_fft<L, 1><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, p, inv_n, inv_wf)
+    SOTS_DISPATCH_LOG2N(log2n, CALL)
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
+                       float *vout, float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d)
+{
+    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    const uint32_t tile = n_pad < kSortTile ? n_pad : kSortTile;
+    const uint32_t tiles = n_pad / tile;
+    k_sort_tiles<<<tiles, kSortThreads, 0, st>>>(fin, keys, p, tile);
+    for (uint32_t k = tile << 1; k <= n_pad && k != 0; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= tile; j >>= 1)
+            k_sort_global_step<<<grid_for(n_pad / 2, 256), 256, 0, st>>>(keys, n_pad, k, j);
+        k_sort_tile_merge<<<tiles, kSortThreads, 0, st>>>(keys, k, tile);
+    }
+    k_sort_gather<<<grid_for((uint64_t)p * (2 * d + 1), 256), 256, 0, st>>>(keys, vin, sin, fin, vout, sout,
+                                                                            fout, p, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_rows(hipStream_t st, const float *values, const float *steps, const float *fitness,
+                            float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d)
+{
+    if (n_rows == 0) return hipSuccess;
+    k_pack_rows<<<grid_for((uint64_t)n_rows * (2 * d + 1), 256), 256, 0, st>>>(values, steps, fitness, rows,
+                                                                               first_row, n_rows, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_rows(hipStream_t st, float *values, float *steps, float *fitness,
+                              const float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d)
+{
+    if (n_rows == 0) return hipSuccess;
+    k_unpack_rows<<<grid_for((uint64_t)n_rows * (2 * d + 1), 256), 256, 0, st>>>(values, steps, fitness, rows,
+                                                                                 first_row, n_rows, d);
+    return hipGetLastError();
+}
+
+} // namespace sots

@@ -1,0 +1,359 @@
+"""GPU parity tests: every HIP stage, called through the C-ABI, against the CPU oracle on
+the same seeded inputs.  Bit-exact for integer/index work and for every fp32 stage whose
+arithmetic is order-fixed (init, recombine, mutate values, synthesis, window, sort);
+stated tolerances for the fp32 FFT/fitness against the oracle's fp64 FFT.
+
+Run with: python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PMAX = {0: [3520.0, 8.0, 3520.0, 1.0],
+        1: [3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0],
+        2: [3520.0, 8.0, 3520.0, 1.0] + [0.0] * 8,
+        3: [3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0]}
+SEED = 0x5EED0001
+
+# fp32 FFT vs fp64 FFT: per-row max |dX| <= FFT_TOL * max|X| (log2(N) rounding layers of ~6e-8)
+FFT_TOL = 3e-6
+# north_star: fitness within 1e-4 relative of the CPU reference; the absolute floor covers
+# near-perfect matches where the sum itself is at rounding level
+FIT_RTOL, FIT_ATOL = 1e-4, 2e-8
+
+
+def make_pair(pkg, O, parents, offspring, kind=0, log2n=10, block=32, gid_base=0, seed=SEED, pmin=None):
+    kw = dict(synth_kind=kind, audio_log2=log2n, param_min=pmin, param_max=PMAX[kind], seed=seed, gid_base=gid_base)
+    es = pkg.HipES(parents, offspring, workgroup_size=block, **kw)
+    ref = O.OracleES(parents, offspring, recomb_block=block, **kw)
+    return es, ref
+
+
+def target_audio(O, kind, n):
+    vals = {0: [1450.0 / 3520.0, 3.0 / 8.0, 200.0 / 3520.0, 1.0],
+            1: [3078 / 3520.0, 2.0 / 8.0, 3015 / 3520.0, 1.5 / 8.0, 3141 / 3520.0, 1.0 / 8.0],
+            2: [0.41, 0.375, 0.057, 1.0, 0.2, 0.5, 0.11, 0.7, 0.6, 0.1, 0.3, 0.4],
+            3: [0.3, 0.25, 0.85, 0.19, 0.89, 0.125, 0.5, 0.1]}[kind]
+    return O.synth(kind, vals, [0.0] * len(vals), PMAX[kind], n), vals
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_init_population_bitexact(pkg, O, kind):
+    es, ref = make_pair(pkg, O, 64, 192, kind, gid_base=1000)
+    for chunk in (0, 3):
+        es.init_population(chunk)
+        ref.init_population(chunk)
+        v, s, f = es.read_population()
+        rv, rs, rf = ref.read_population()
+        assert np.array_equal(v, rv)
+        assert np.array_equal(s, rs)
+        assert np.array_equal(f, rf)
+        assert v.min() >= 0.0 and v.max() <= 1.0
+    es.close()
+
+
+@pytest.mark.parametrize("parents,offspring,block,kind", [
+    (64, 192, 32, 0), (16, 16, 32, 1), (256, 768, 64, 0), (96, 160, 32, 2), (128, 384, 128, 3), (3, 5, 1, 0)])
+def test_recombine_bitexact(pkg, O, parents, offspring, block, kind):
+    es, ref = make_pair(pkg, O, parents, offspring, kind, block=block)
+    rng = np.random.default_rng(7)
+    P, D = es.P, es.D
+    v = rng.random((P, D), dtype=np.float32)
+    s = rng.random((P, D), dtype=np.float32)
+    es.write_population(v, s, np.zeros(P, np.float32))
+    es.recombine()
+    gv, gs, _ = es.read_population()
+    ev, es_ = O.recombine(v, s, parents, block)
+    assert np.array_equal(gv, ev)
+    assert np.array_equal(gs, es_)
+    # the source half is untouched (out-of-place)
+    ov, os_, _ = es.read_population(other=True)
+    assert np.array_equal(ov, v) and np.array_equal(os_, s)
+    es.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_mutate_values_bitexact_steps_close(pkg, O, kind):
+    es, ref = make_pair(pkg, O, 64, 192, kind, gid_base=77)
+    rng = np.random.default_rng(11)
+    P, D = es.P, es.D
+    v = rng.random((P, D), dtype=np.float32)
+    s = (rng.random((P, D), dtype=np.float32) * 0.5 + 0.01).astype(np.float32)
+    s[0, :] = 3.0  # large steps force the reflect branch (ocl_program.cl:176-182)
+    for gen in (0, 1, 1234):
+        es.write_population(v, s, None)
+        es.generation = gen
+        es.mutate()
+        gv, gs, _ = es.read_population()
+        ev, es_ = O.mutate(v, s, SEED, 77, gen)
+        assert np.array_equal(gv, ev), f"values differ at generation {gen}"
+        # exp/pow are libm on the CPU and ocml on the device: a few ulp
+        np.testing.assert_allclose(gs, es_, rtol=2e-6, atol=0)
+    es.close()
+
+
+@pytest.mark.parametrize("kind,log2n", [(0, 10), (1, 11), (2, 10), (3, 12), (0, 9), (0, 13)])
+def test_synthesise_bitexact(pkg, O, kind, log2n):
+    es, ref = make_pair(pkg, O, 64, 192, kind, log2n)
+    es.init_population(0)
+    ref.init_population(0)
+    v, s, _ = es.read_population()
+    # plant the reference's known parameter sets and the corners of the unit cube
+    _, tv = target_audio(O, kind, es.N)
+    v[0] = tv
+    v[1] = 0.0
+    v[2] = 1.0
+    es.write_population(v, s, None)
+    ref.write_population(v, s, None)
+    es.synthesise()
+    ref.evaluate()
+    assert np.array_equal(es.read_audio(), ref.audio())
+    es.close()
+
+
+def test_synthesise_nonzero_param_min(pkg, O):
+    pmin = [100.0, 0.5, 50.0, 0.1]
+    es, ref = make_pair(pkg, O, 32, 32, 0, 10, pmin=pmin)
+    es.init_population(0)
+    ref.init_population(0)
+    es.synthesise()
+    ref.evaluate()
+    assert np.array_equal(es.read_audio(), ref.audio())
+    es.close()
+
+
+def test_window_bitexact(pkg, O):
+    es, _ = make_pair(pkg, O, 32, 96, 0, 10)
+    rng = np.random.default_rng(3)
+    a = (rng.random((es.P, es.N), dtype=np.float32) * 2 - 1).astype(np.float32)
+    es.write_audio(a)
+    es.window()
+    w64, wf = O.window(es.N)
+    expect = a * w64.astype(np.float32)[None, :]
+    assert np.array_equal(es.read_audio(), expect)
+    assert wf == np.float32(1.0)
+    es.close()
+
+
+@pytest.mark.parametrize("log2n", [9, 10, 11, 12, 13])
+def test_fft_against_fp64(pkg, O, log2n):
+    es, _ = make_pair(pkg, O, 16, 48, 0, log2n)
+    rng = np.random.default_rng(log2n)
+    n = es.N
+    a = (rng.standard_normal((es.P, n))).astype(np.float32)
+    a[0] = 0.0
+    a[1] = 1.0                      # DC only
+    a[2] = np.cos(2 * np.pi * 5 * np.arange(n) / n)   # single bin
+    a[3] = (-1.0) ** np.arange(n)   # Nyquist only
+    a[4] = 0.0; a[4, 0] = 1.0       # impulse: flat spectrum
+    es.write_audio(a)
+    es.fft()
+    spec = es.read_spectrum()
+    assert spec.shape == (es.P, n // 2 + 4)
+    ones = np.ones(n)
+    for i in range(es.P):
+        ref = O.rfft(a[i], ones)
+        got = spec[i, : n // 2 + 1].astype(np.complex128)
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= FFT_TOL * scale, f"row {i}"
+        assert np.all(spec[i, n // 2 + 1:] == 0)  # padding bins stay zero
+    es.close()
+
+
+@pytest.mark.parametrize("kind,log2n", [(0, 10), (1, 11), (3, 12), (2, 10)])
+def test_fitness_staged_and_fused_against_oracle(pkg, O, kind, log2n):
+    es, ref = make_pair(pkg, O, 64, 192, kind, log2n)
+    tgt, tv = target_audio(O, kind, es.N)
+    es.set_target_audio(tgt)
+    ref.set_target_audio(tgt)
+    np.testing.assert_allclose(es.read_target(), O.spectrum(tgt), rtol=1e-6, atol=1e-9)
+    es.init_population(0)
+    ref.init_population(0)
+    v, s, _ = es.read_population()
+    v[5] = tv  # self-match row
+    es.write_population(v, s, None)
+    ref.write_population(v, s, None)
+    ref.evaluate()
+    _, _, rf = ref.read_population()
+    # staged: synth -> window -> fft -> fitness
+    es.synthesise(); es.window(); es.fft(); es.fitness()
+    f_staged = es.read_fitness()
+    np.testing.assert_allclose(f_staged, rf, rtol=FIT_RTOL, atol=FIT_ATOL)
+    # magnitudes of the materialised spectrum against the oracle's
+    spec = es.read_spectrum()[:, : es.N // 2]
+    mag = np.abs(spec.astype(np.complex128)) / es.N
+    np.testing.assert_allclose(mag, ref.spectrum(), rtol=0, atol=3e-6 * max(1.0, np.abs(ref.spectrum()).max()))
+    # self-match KAT (ocl_program.cl:247-250): fitness of the true parameters is ~0
+    assert rf[5] == 0.0
+    assert f_staged[5] <= FIT_ATOL
+    es.close()
+
+
+def sort_case(P, rng):
+    f = rng.random(P, dtype=np.float32)
+    if P >= 16:
+        f[3] = f[11]                # ties
+        f[5] = f[7] = f[9]
+        f[2] = np.nan
+        f[P - 1] = np.nan
+        f[4] = np.inf
+        f[6] = 0.0
+        f[8] = -0.0
+        f[10] = 0.0
+    return f
+
+
+@pytest.mark.parametrize("parents,offspring,block", [
+    (16, 16, 32), (64, 192, 32), (24, 72, 32), (256, 768, 32), (1024, 3072, 32), (2048, 6144 + 32, 32),
+    (16384, 49152, 32)])
+def test_sort_matches_stable_oracle(pkg, O, parents, offspring, block):
+    es, _ = make_pair(pkg, O, parents, offspring, 0, 10, block=block)
+    rng = np.random.default_rng(parents)
+    P, D = es.P, es.D
+    f = sort_case(P, rng)
+    if P > 4096:
+        f[::97] = f[5]              # many duplicates across tiles
+    v = rng.random((P, D), dtype=np.float32)
+    s = rng.random((P, D), dtype=np.float32)
+    es.write_population(v, s, f)
+    es.sort(); es.rotate()
+    gv, gs, gf = es.read_population()
+    perm = O.sort_perm(f)
+    assert np.array_equal(gf, f[perm], equal_nan=True)
+    assert np.array_equal(gv, v[perm])
+    assert np.array_equal(gs, s[perm])
+    es.close()
+
+
+@pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (3, 12, 32, 96), (2, 10, 32, 96)])
+def test_fused_generation_equals_staged(pkg, O, kind, log2n, parents, offspring):
+    a, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    b, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    tgt, _ = target_audio(O, kind, a.N)
+    for es in (a, b):
+        es.set_target_audio(tgt)
+        es.init_population(0)
+    for _ in range(3):
+        a.execute_generation()
+    b.execute_generations(3)
+    assert a.generation == b.generation == 3
+    for x, y in zip(a.read_population(), b.read_population()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
+def test_config2_trajectory_per_generation_parity(pkg, O):
+    """BASELINE config 2: P=1024 (256+768), 2-op, N=1024.  Each generation the oracle is
+    re-synchronised to the device's pre-generation state, runs the same generation, and both
+    results must agree stage by stage."""
+    es, ref = make_pair(pkg, O, 256, 768, 0, 10)
+    tgt, _ = target_audio(O, 0, es.N)
+    es.set_target_audio(tgt)
+    ref.set_target_audio(tgt)
+    es.init_population(0)
+    best = []
+    for gen in range(20):
+        v, s, f = es.read_population()
+        ref.write_population(v, s, f)
+        ref.set_generation(gen)
+        es.recombine(); es.mutate()
+        ref.recombine(); ref.mutate()
+        gv, gs, _ = es.read_population()
+        rv, rs, _ = ref.read_population()
+        assert np.array_equal(gv, rv), f"gen {gen}"
+        np.testing.assert_allclose(gs, rs, rtol=2e-6, atol=0)
+        ref.write_population(gv, gs, None)  # carry the device's steps so values stay bit-exact
+        es.synthesise(); es.window(); es.fft(); es.fitness()
+        ref.evaluate()
+        gf = es.read_fitness()
+        _, _, rf = ref.read_population()
+        np.testing.assert_allclose(gf, rf, rtol=FIT_RTOL, atol=FIT_ATOL)
+        es.sort(); es.rotate()
+        sv, ss, sf = es.read_population()
+        perm = O.sort_perm(gf)
+        assert np.array_equal(sf, gf[perm]) and np.array_equal(sv, gv[perm]) and np.array_equal(ss, gs[perm])
+        best.append(float(sf[0]))
+    assert es.generation == 20
+    # (mu + lambda)-style selection on a re-evaluated population is not monotone, but the search
+    # must make progress on this easy target
+    assert min(best) < best[0]
+    es.close()
+
+
+def test_full_size_properties_config3(pkg, O):
+    """BASELINE config 3 (P=65536, 2-op, N=1024): size-independent properties."""
+    es, _ = make_pair(pkg, O, 16384, 49152, 0, 10)
+    tgt, tv = target_audio(O, 0, es.N)
+    es.set_target_audio(tgt)
+    es.init_population(0)
+    es.execute_generations(2)
+    v, s, f = es.read_population()
+    assert np.all(np.diff(f) >= 0), "population not sorted by fitness"
+    assert np.all(np.isfinite(f)) and f[0] >= 0
+    # one more generation staged, with a planted perfect individual: it must come out first
+    es.recombine(); es.mutate()
+    v, s, _ = es.read_population()
+    v[12345] = tv
+    es.write_population(v, s, None)
+    es.synthesise(); es.window(); es.fft(); es.fitness()
+    fu = es.read_fitness()
+    es.sort(); es.rotate()
+    v2, s2, f2 = es.read_population()
+    assert f2[0] <= FIT_ATOL and np.array_equal(v2[0], v[12345])
+    # sorted output is a permutation of the input rows (checksum of checksums)
+    assert np.array_equal(np.sort(fu), f2)
+    key_in = np.sort(v.astype(np.float64) @ np.array([1.0, 3.0, 7.0, 11.0]))
+    key_out = np.sort(v2.astype(np.float64) @ np.array([1.0, 3.0, 7.0, 11.0]))
+    assert np.array_equal(key_in, key_out)
+    # spot-check 64 random rows of the full-size evaluation against the oracle
+    rng = np.random.default_rng(5)
+    rows = rng.choice(es.P, 64, replace=False)
+    tgt_mag = O.spectrum(tgt)
+    for r in rows:
+        a = O.synth(0, v[r], [0.0] * 4, PMAX[0], es.N)
+        want = O.fitness(O.spectrum(a), tgt_mag)
+        assert abs(fu[r] - want) <= FIT_RTOL * want + FIT_ATOL
+    es.close()
+
+
+def test_island_rows_roundtrip(pkg, O):
+    es, ref = make_pair(pkg, O, 64, 192, 0, 10)
+    rng = np.random.default_rng(9)
+    v = rng.random((es.P, es.D), dtype=np.float32)
+    s = rng.random((es.P, es.D), dtype=np.float32)
+    f = np.sort(rng.random(es.P, dtype=np.float32))
+    es.write_population(v, s, f)
+    ref.write_population(v, s, f)
+    rows = es.pack_elites(16)
+    assert np.array_equal(rows, ref.pack_elites(16))
+    imm = rng.random((48, 2 * es.D + 1), dtype=np.float32)
+    es.inject_immigrants(imm)
+    ref.inject(imm)
+    for x, y in zip(es.read_population(), ref.read_population()):
+        assert np.array_equal(x, y)
+    es.close()
+
+
+def test_stage_timers_and_errors(pkg, O):
+    es, _ = make_pair(pkg, O, 64, 192, 0, 10)
+    with pytest.raises(pkg.SotsError) as e:
+        es.execute_generation()     # no target yet
+    assert e.value.code == -5
+    tgt, _ = target_audio(O, 0, es.N)
+    es.set_target_audio(tgt)
+    es.init_population(0)
+    es.timing_enable(True)
+    es.execute_generation()
+    es.execute_generations(2)
+    for st in (pkg.capi.STAGE_RECOMBINE, pkg.capi.STAGE_SYNTHESISE, pkg.capi.STAGE_FFT, pkg.capi.STAGE_FITNESS):
+        ms, cnt = es.stage_time_ms(st)
+        assert cnt == 1 and ms > 0
+    ms, cnt = es.stage_time_ms(pkg.capi.STAGE_SORT)
+    assert cnt == 3
+    ms, cnt = es.stage_time_ms(pkg.capi.STAGE_FUSED_SPECTRAL)
+    assert cnt == 2 and ms > 0
+    with pytest.raises(pkg.SotsError) as e:
+        es.set_target_spectrum(np.zeros(7, np.float32))
+    assert e.value.code == -4
+    es.close()
