@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- candidates evaluated per second of the evolutionary FM-matching loop.
+
+A "step" is one generation (recombine+mutate | synthesise+window | FFT+fitness | sort |
+rotate, plus the elite all-gather when N > 1) over one island's whole population.
+Workload at N = 1: BASELINE.json configs[2] -- pop = 65536 (16384 parents + 49152
+offspring), 2-operator FM, 1024-sample / 1024-pt FFT, fp32, synthetic target
+(1450 Hz, I = 3, 200 Hz, A = 1).  N > 1: one island of that size per GPU (weak scaling),
+one process per GPU, elites all-gathered over RCCL every generation.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "survival_of_the_synthesis-gpu_accelerated_frequency_modulation_parameter_matcher_amd"
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+PARAM_MAX = [3520.0, 8.0, 3520.0, 1.0]
+TARGET_PARAMS = [1450.0 / 3520.0, 3.0 / 8.0, 200.0 / 3520.0, 1.0]
+
+
+def make_target(pkg, log2n, device):
+    """Target audio from the HIP synthesiser itself (the oracle is not used on the product path)."""
+    es = pkg.HipES(32, 32, pkg.capi.SYNTH_2OP, log2n, None, PARAM_MAX, seed=1, workgroup_size=32, device=device)
+    v = np.tile(np.asarray(TARGET_PARAMS, np.float32), (es.P, 1))
+    es.write_population(v, np.full_like(v, 0.1), None)
+    es.synthesise()
+    audio = es.read_audio()[0].copy()
+    es.close()
+    return audio
+
+
+def cpu_baseline(log2n, target_audio, budget_s=12.0):
+    """The CPU oracle (oracle/sots_oracle.c, a single-threaded port of the reference's
+    Evolutionary_Strategy_CPU path) timed on this host on a bounded sample of the workload."""
+    from oracle import oracle as O
+    parents, offspring = 512, 1536
+    ref = O.OracleES(parents, offspring, O.SYNTH_2OP, log2n, None, PARAM_MAX, seed=0x5EED0001, recomb_block=32)
+    ref.set_target_audio(target_audio)
+    ref.init_population(0)
+    t0 = time.perf_counter()
+    ref.generation()
+    one = time.perf_counter() - t0
+    gens = max(2, min(200, int(budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(gens):
+        ref.generation()
+    dt = time.perf_counter() - t0
+    p = parents + offspring
+    return {"value": p * gens / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
+            "sample": f"pop={p} x {gens} generations, 2-op FM, N={1 << log2n}, fp64 built-in FFT "
+                      f"(FFTW unavailable), {dt:.1f} s on 1 core"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--parents", type=int, default=16384)
+    ap.add_argument("--offspring", type=int, default=49152)
+    ap.add_argument("--log2n", type=int, default=10)
+    ap.add_argument("--elites", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pkg = importlib.import_module(PKG)
+    P = args.parents + args.offspring
+    N = 1 << args.log2n
+    target = make_target(pkg, args.log2n, local_rank)
+    es = pkg.HipES(args.parents, args.offspring, pkg.capi.SYNTH_2OP, args.log2n, None, PARAM_MAX,
+                   seed=0x5EED0001, workgroup_size=32, device=local_rank, gid_base=rank * P,
+                   num_generations=args.steps)
+    stream = torch.cuda.Stream(device=device)
+    es.set_stream(stream.cuda_stream)
+    es.set_target_audio(target)
+    island = pkg.island.IslandExchange(rank, world, args.elites, es.D, device)
+
+    def step():
+        es.execute_generations(1)
+        island.migrate_device(es)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.cuda.stream(stream):
+        es.init_population(0)
+        for _ in range(args.warmup):
+            step()
+        es.timing_enable(True)
+        es.timing_reset()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+    es.timing_enable(False)
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt_max = float(dt_t.item())
+
+    # per-kernel device time (HIP events on the launch stream, recorded inside the timed region)
+    c = pkg.capi
+    kernels = {}
+    for name, stage, alg_bytes in (
+            ("recombine+mutate", c.STAGE_FUSED_VARIATION, 16 * es.D),
+            # synth write 4N + window read/write 8N
+            ("synthesise+window", c.STAGE_FUSED_SYNTH, 12 * N),
+            # FFT read 4N + write 8(N/2+1), fitness read 8(N/2+1)
+            ("FFT+fitness", c.STAGE_FUSED_SPECTRAL, 12 * N + 16),
+            ("sortPopulation", c.STAGE_SORT, 16 + 8 * (2 * es.D + 1))):
+        ms, cnt = es.stage_time_ms(stage)
+        if cnt:
+            kernels[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt), "alg_bytes_per_candidate": alg_bytes}
+    fitness = es.read_fitness()
+    best = float(fitness[0])
+
+    if rank == 0:
+        value = P * world * args.steps / dt_max
+        dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+        dk = kernels[dom]
+        achieved = dk["alg_bytes_per_candidate"] * P / (dk["avg_us"] * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        b_alg = 24 * N + 16
+        out = {
+            "metric": "candidates evaluated/sec (pop x gens / s)",
+            "value": value,
+            "unit": "candidates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: pop={P} ({args.parents}+{args.offspring}) per GPU, 2-op FM, "
+                                   f"{N}-sample / {N}-pt FFT, fp32",
+                       "islands": world, "elites_per_island": args.elites if world > 1 else 0,
+                       "migration_interval": 1, "parallelism": f"island x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_kernel_us": dk["avg_us"],
+                         "alg_bytes_per_launch": dk["alg_bytes_per_candidate"] * P},
+            "pipeline_effective": {"b_alg_bytes_per_candidate": b_alg,
+                                   "effective_GBs_per_gpu": value / world * b_alg / 1e9,
+                                   "frac_of_hbm_peak": value / world * b_alg / 1e9 / HBM_PEAK_GBS,
+                                   "note": "window fused into synth and the spectrum never materialised: the loop moves "
+                                           "8N bytes per candidate, not B_alg = 24N+16, so this is an effective figure"},
+            "kernels": kernels,
+            "best_fitness_sse": best,
+            "best_fitness_mse": best / (N // 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.log2n, target)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    es.close()
+
+
+if __name__ == "__main__":
+    main()
