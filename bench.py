@@ -55,7 +55,7 @@ def cpu_baseline(log2n, target_audio, budget_s=12.0):
     t0 = time.perf_counter()
     ref.generation()
     one = time.perf_counter() - t0
-    gens = max(2, min(200, int(budget_s / max(one, 1e-6))))
+    gens = max(2, min(5000, int(budget_s / max(one, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(gens):
         ref.generation()
