@@ -1,0 +1,130 @@
+// Benchmarker.hpp -- named timers with the reference's interface (Benchmarker.hpp:12-167):
+// startTimer/pauseTimer around a blocking stage, or addTimer(name, ms) for durations that
+// were measured elsewhere (the Vulkan backend feeds GPU timestamp queries that way,
+// Evolutionary_Strategy_Vulkan.hpp:1169-1210; the HIP backend feeds hipEvent times).
+// elapsedTimer(name) prints the totals, appends one CSV row
+//   Test_Name,Total_Time,Average_Time,Max_Time,Min_Time,Max_Difference,Average_Difference
+// (all in ms) and resets the timer.
+//
+// One deliberate difference: the reference builds a 6-field record when a timer fired at
+// most once and CSV_Logger then drops it (Benchmarker.hpp:145-157, CSV_Logger.hpp:30-31);
+// here every timer produces a full 7-field row.
+#ifndef SOTS_BENCHMARKER_HPP
+#define SOTS_BENCHMARKER_HPP
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "CSV_Logger.hpp"
+
+class Benchmarker
+{
+    struct Timer {
+        double start = 0.0, total = 0.0, last = 0.0;
+        double maxDuration = 0.0, minDuration = 9999999.0;
+        double maxDifference = 0.0, sumDifference = 0.0;
+        uint32_t count = 0;
+    };
+    std::map<std::string, Timer> timers_;
+    CSV_Logger logger_;
+    bool verbose_ = true;
+
+    static double nowMs()
+    {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    static void fold(Timer &t, double elapsed)
+    {
+        const double diff = std::fabs(elapsed - t.last);
+        t.sumDifference += diff;
+        t.last = elapsed;
+        if (diff > t.maxDifference) t.maxDifference = diff;
+        if (elapsed > t.maxDuration) t.maxDuration = elapsed;
+        if (elapsed < t.minDuration) t.minDuration = elapsed;
+    }
+    Timer &begin(const std::string &name)
+    {
+        Timer &t = timers_[name];
+        if (t.count == 0) {
+            t.maxDifference = 0.0;
+            t.maxDuration = 0.0;
+            t.minDuration = 9999999.0;
+        }
+        ++t.count;
+        return t;
+    }
+
+public:
+    Benchmarker(const std::string aPath, const std::vector<std::string> aFields) : logger_(aPath, aFields) {}
+
+    void setVerbose(bool v) { verbose_ = v; }
+
+    // wall-clock timers
+    void startTimer(const std::string aTimer) { begin(aTimer).start = nowMs(); }
+    void waitTimer(const std::string aTimer)
+    {
+        Timer &t = timers_[aTimer];
+        t.total += nowMs() - t.start;
+    }
+    void resumeTimer(const std::string aTimer) { timers_[aTimer].start = nowMs(); }
+    void pauseTimer(const std::string aTimer) { pauseTimer(aTimer, nowMs()); }
+    void endTimer(const std::string aTimer) { waitTimer(aTimer); }
+
+    // caller-supplied timestamps (ms)
+    void startTimer(const std::string aTimer, double aTimestamp) { begin(aTimer).start = aTimestamp; }
+    void pauseTimer(const std::string aTimer, double aTimestamp)
+    {
+        Timer &t = timers_[aTimer];
+        const double elapsed = aTimestamp - t.start;
+        t.total += elapsed;
+        fold(t, elapsed);
+    }
+    // a duration measured elsewhere (ms)
+    void addTimer(const std::string aTimer, double aDurationMs)
+    {
+        Timer &t = begin(aTimer);
+        t.total += aDurationMs;
+        fold(t, aDurationMs);
+    }
+
+    double totalMs(const std::string &aTimer) const
+    {
+        auto it = timers_.find(aTimer);
+        return it == timers_.end() ? 0.0 : it->second.total;
+    }
+    uint32_t count(const std::string &aTimer) const
+    {
+        auto it = timers_.find(aTimer);
+        return it == timers_.end() ? 0u : it->second.count;
+    }
+
+    void elapsedTimer(const std::string aTimer)
+    {
+        Timer &t = timers_[aTimer];
+        const double n = t.count > 0 ? (double)t.count : 1.0;
+        const double average = t.total / n;
+        if (verbose_) {
+            std::cout << "Benchmarker: " << aTimer << std::endl;
+            std::cout << "Total time to complete: " << t.total / 1e3 << "s" << std::endl;
+            std::cout << "Total time to complete: " << t.total << "ms" << std::endl;
+            std::cout << "Total time to complete: " << t.total * 1e6 << "ns" << std::endl;
+            std::cout << "Average time to complete each buffer: " << average << "ms" << std::endl << std::endl;
+        }
+        logger_.addRecord({aTimer, std::to_string(t.total), std::to_string(average), std::to_string(t.maxDuration),
+                           std::to_string(t.minDuration), std::to_string(t.maxDifference),
+                           std::to_string(t.sumDifference / n)});
+        t = Timer();
+    }
+    bool close()
+    {
+        logger_.close();
+        return true;
+    }
+};
+
+#endif
