@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     const std::string dir = argc > 1 ? argv[1] : ".";
     try {
         const std::vector<float> pmax = {3520.0f, 8.0f, 3520.0f, 1.0f};
-        const uint32_t parents = 256, offspring = 768, gens = 40, log2n = 10, n = 1u << log2n;
+        const uint32_t parents = 2048, offspring = 6144, gens = 40, log2n = 10, n = 1u << log2n;
         auto args = make_args(parents, offspring, 4, log2n, gens, pmax, dir);
         std::unique_ptr<Evolutionary_Strategy> es(new Evolutionary_Strategy_HIP(args));
 

@@ -24,9 +24,10 @@ def test_evolutionary_strategy_hip_through_base_class(tmp_path):
     assert r["chunks"] == 2
     assert r["csv_header"].startswith("Test_Name,Total_Time,Average_Time,Max_Time,Min_Time,Max_Difference,Average_Difference")
     assert r["csv_has_total"] and r["csv_rows"] >= 4
-    # 40 generations of 1024 candidates get well below the fitness of a random candidate (~1e-1)
-    assert r["best_fitness_last_chunk"] < 2e-2
-    assert r["host_fitness_chunk0"] < 2e-2
+    # 40 generations of 8192 candidates: the CPU oracle reaches 3.3e-9 on chunk 0 and the local
+    # optimum 0.0258 on chunk 1 with this seed; the best of a random population is ~0.1-0.3
+    assert r["host_fitness_chunk0"] < 1e-6
+    assert r["best_fitness_last_chunk"] < 3e-2
 
 
 def read_wav24(path):
@@ -46,14 +47,15 @@ def test_sots_match_cli(tmp_path, O):
     cfg = json.load(open(os.path.join(PKG_DIR, "parameters.json")))
     cfg["general"]["outputAudioPath"] = str(tmp_path / "out.wav")
     cfg["general"]["isDebug"] = False
-    cfg["evolutionary"]["numGenerations"] = 60
+    cfg["evolutionary"]["numGenerations"] = 40
+    cfg["evolutionary"]["numParents"], cfg["evolutionary"]["numOffspring"] = 2048, 6144
     p = tmp_path / "parameters.json"
     p.write_text(json.dumps(cfg))
     out = subprocess.run([exe, "-j", str(p)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert out.returncode == 0, out.stderr
     assert "Overall best parameters found" in out.stdout
     fit = float(out.stdout.split("Fitness = ")[1].split()[0])
-    assert fit < 2e-2
+    assert fit < 1e-6
     fmt, ch, rate, bits, gen = read_wav24(tmp_path / "inputGenerated.wav")
     assert (fmt, ch, rate, bits) == (1, 1, 44100, 24) and len(gen) == 1024
     want = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, [3520.0, 8.0, 3520.0, 1.0], 1024)
@@ -71,7 +73,7 @@ def test_sots_match_cli(tmp_path, O):
     p.write_text(json.dumps(cfg))
     out = subprocess.run([exe, "-j", str(p)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert out.returncode == 0, out.stderr
-    assert float(out.stdout.split("Fitness = ")[1].split()[0]) < 2e-2
+    assert float(out.stdout.split("Fitness = ")[1].split()[0]) < 3e-2
     # wrong implementation is refused
     cfg["type"]["implementation"] = "OpenCL"
     p.write_text(json.dumps(cfg))
