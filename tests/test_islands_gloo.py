@@ -1,0 +1,73 @@
+"""The N > 1 path on CPU: world_size-2 and -3 island runs over gloo, one process per island,
+checked against a single-process simulation of the same islands.  The evaluator is the CPU
+oracle; the exchange code (island.IslandExchange) is the one bench.py uses over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def simulate(O, world, gens, elites):
+    pmax = [3520.0, 8.0, 3520.0, 1.0]
+    tgt = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, pmax, 1024)
+    isl = []
+    for r in range(world):
+        es = O.OracleES(32, 96, O.SYNTH_2OP, 10, None, pmax, seed=0x5EED0001, recomb_block=32, gid_base=r * 128)
+        es.set_target_audio(tgt)
+        es.init_population(0)
+        isl.append(es)
+    for _ in range(gens):
+        for es in isl:
+            es.generation()
+        packs = [es.pack_elites(elites) for es in isl]
+        for r, es in enumerate(isl):
+            es.inject(np.concatenate([packs[q] for q in range(world) if q != r]))
+    return [es.read_population() for es in isl]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_island_exchange_over_gloo(tmp_path, O, world):
+    gens, elites = 4, 4
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_island_worker.py"),
+                                       str(tmp_path), str(gens), str(elites)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode()
+    want = simulate(O, world, gens, elites)
+    got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(got[r]["v"], want[r][0])
+        assert np.array_equal(got[r]["s"], want[r][1])
+        assert np.array_equal(got[r]["f"], want[r][2])
+    # every island's parent tail holds the other islands' last elites, in rank order
+    for r in range(world):
+        others = np.concatenate([got[q]["sent"][-1] for q in range(world) if q != r])
+        n = others.shape[0]
+        assert np.array_equal(got[r]["f"][32 - n:32], others[:, 0])
+        assert np.array_equal(got[r]["v"][32 - n:32], others[:, 1:5])
+    # islands are distinct streams (global individual ids differ)
+    assert not np.array_equal(got[0]["v"], got[1]["v"])
+
+
+def test_single_island_is_a_no_op(O, pkg):
+    ex = pkg.island.IslandExchange(0, 1, 4, 4, "cpu")
+    calls = []
+    ex.migrate_host(lambda n: calls.append(n), lambda rows: calls.append(rows))
+    assert calls == [] and ex.num_immigrants == 0
