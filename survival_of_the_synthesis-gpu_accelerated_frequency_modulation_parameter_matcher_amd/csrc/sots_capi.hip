@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,6 +39,7 @@ struct sots_ctx {
     uint32_t num_cus = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint32_t P = 0, D = 0, N = 0, log2n = 0, n_pad = 0;
+    uint32_t pitch = 0; // floats between audio rows on the device (>= N)
     uint32_t rot = 0, generation = 0;
     bool target_set = false;
     // device buffers
@@ -262,6 +264,13 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     ctx->log2n = cfg->audio_length_log2;
     ctx->N = 1u << ctx->log2n;
     ctx->n_pad = next_pow2(ctx->P < 2 ? 2 : ctx->P);
+    {
+        // audio rows are padded off the power-of-two stride (see sots_kernels.h); SOTS_AUDIO_PAD
+        // (floats, multiple of 4) overrides the default for experiments
+        uint32_t pad = 32;
+        if (const char *e = getenv("SOTS_AUDIO_PAD")) pad = (uint32_t)strtoul(e, nullptr, 10) & ~3u;
+        ctx->pitch = ctx->N + pad;
+    }
     ctx->pd = PopDims{ctx->P, ctx->D, cfg->num_parents, cfg->workgroup_size, cfg->gid_base,
                       (uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
     // Evolutionary_Strategy.hpp:611-627
@@ -277,7 +286,7 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     memcpy(ctx->sp.pmax, cfg->param_max, sizeof ctx->sp.pmax);
 
     const size_t pd_bytes = (size_t)2 * ctx->P * ctx->D * sizeof(float);
-    const size_t audio_bytes = (size_t)ctx->P * ctx->N * sizeof(float);
+    const size_t audio_bytes = (size_t)ctx->P * ctx->pitch * sizeof(float);
     const size_t spec_bytes = (size_t)ctx->P * (ctx->N + 8) * sizeof(float);
     CREATE_HIP(hipMalloc((void **)&ctx->values, pd_bytes));
     CREATE_HIP(hipMalloc((void **)&ctx->steps, pd_bytes));
@@ -422,7 +431,9 @@ int sots_write_synth(sots_ctx *ctx, const float *audio, size_t audio_bytes, cons
     if ((audio && audio_bytes != a_bytes) || (spectrum && spectrum_bytes != s_bytes))
         return fail(ctx, SOTS_ERR_SIZE, "synth byte counts must be %zu (audio) and %zu (spectrum)", a_bytes, s_bytes);
     if (int rc = bind_device(ctx)) return rc;
-    if (audio) SOTS_HIP(ctx, hipMemcpyAsync(ctx->audio, audio, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (audio)
+        SOTS_HIP(ctx, hipMemcpy2DAsync(ctx->audio, (size_t)ctx->pitch * sizeof(float), audio, (size_t)ctx->N * sizeof(float),
+                                       (size_t)ctx->N * sizeof(float), ctx->P, hipMemcpyHostToDevice, ctx->stream));
     if (spectrum) SOTS_HIP(ctx, hipMemcpyAsync(ctx->spectrum, spectrum, s_bytes, hipMemcpyHostToDevice, ctx->stream));
     SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SOTS_OK;
@@ -438,7 +449,9 @@ int sots_read_synth(sots_ctx *ctx, float *audio, size_t audio_bytes, float *spec
         return fail(ctx, SOTS_ERR_SIZE, "synth byte counts must be %zu (audio), %zu (spectrum), %zu (target)",
                     a_bytes, s_bytes, t_bytes);
     if (int rc = bind_device(ctx)) return rc;
-    if (audio) SOTS_HIP(ctx, hipMemcpyAsync(audio, ctx->audio, a_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (audio)
+        SOTS_HIP(ctx, hipMemcpy2DAsync(audio, (size_t)ctx->N * sizeof(float), ctx->audio, (size_t)ctx->pitch * sizeof(float),
+                                       (size_t)ctx->N * sizeof(float), ctx->P, hipMemcpyDeviceToHost, ctx->stream));
     if (spectrum) SOTS_HIP(ctx, hipMemcpyAsync(spectrum, ctx->spectrum, s_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (target) SOTS_HIP(ctx, hipMemcpyAsync(target, ctx->target, t_bytes, hipMemcpyDeviceToHost, ctx->stream));
     SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -477,7 +490,7 @@ int sots_stage_synthesise(sots_ctx *ctx)
     {
         StageScope t(ctx, SOTS_STAGE_SYNTHESISE);
         SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, nullptr,
-                                   ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->num_cus));
+                                   ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
     }
     return maybe_drain(ctx);
 }
@@ -488,7 +501,7 @@ int sots_stage_window(sots_ctx *ctx)
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_WINDOW);
-        SOTS_HIP(ctx, launch_window(ctx->stream, ctx->audio, ctx->window, ctx->P, ctx->log2n));
+        SOTS_HIP(ctx, launch_window(ctx->stream, ctx->audio, ctx->window, ctx->P, ctx->log2n, ctx->pitch));
     }
     return maybe_drain(ctx);
 }
@@ -499,7 +512,7 @@ int sots_stage_fft(sots_ctx *ctx)
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_FFT);
-        SOTS_HIP(ctx, launch_fft(ctx->stream, ctx->audio, ctx->spectrum, ctx->twiddle, ctx->P, ctx->log2n, ctx->num_cus));
+        SOTS_HIP(ctx, launch_fft(ctx->stream, ctx->audio, ctx->spectrum, ctx->twiddle, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
     }
     return maybe_drain(ctx);
 }
@@ -571,12 +584,12 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH);
             SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, ctx->window,
-                                       ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->num_cus));
+                                       ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
         }
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL);
             SOTS_HIP(ctx, launch_fft_fitness(ctx->stream, ctx->audio, ctx->target, ctx->fit(ctx->rot), ctx->twiddle, ctx->P,
-                                             ctx->log2n, ctx->inv_n, ctx->inv_wf, ctx->num_cus));
+                                             ctx->log2n, ctx->pitch, ctx->inv_n, ctx->inv_wf, ctx->num_cus));
         }
         src = ctx->rot;
         dst = ctx->rot ^ 1u;

@@ -48,20 +48,23 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
                                    uint32_t generation);
 
 // ---- evaluation ----
+// Audio rows are `pitch` floats apart (pitch >= N, a multiple of 4): a power-of-two row stride
+// would put every lane of a row-per-lane store on the same memory channel.
 // window == nullptr: raw synthesis; else audio is multiplied by the fp32 window on the way out
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         const float *window, float *audio, const SynthParams &sp, uint32_t p,
-                        uint32_t log2n, uint32_t num_cus);
-hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n);
-// audio[P][N] -> spectrum[P][N+8]
+                        uint32_t log2n, uint32_t pitch, uint32_t num_cus);
+hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n,
+                         uint32_t pitch);
+// audio[P][pitch] -> spectrum[P][N+8]
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
-                      uint32_t p, uint32_t log2n, uint32_t num_cus);
+                      uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus);
 // spectrum[P][N+8] x target[N/2] -> fitness[P]
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus);
 // audio[P][N] x target -> fitness[P] without materialising the spectrum
 hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *target, float *fitness,
-                              const float2 *twiddle, uint32_t p, uint32_t log2n, float inv_n,
+                              const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch, float inv_n,
                               float inv_wf, uint32_t num_cus);
 
 // ---- selection ----

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                                                          const float *__restrict__ wavetable,
                                                          const float *__restrict__ window,
                                                          float *__restrict__ audio, SynthParams sp,
-                                                         uint32_t p_len, uint32_t n)
+                                                         uint32_t p_len, uint32_t n, uint32_t pitch)
 {
     __shared__ float tab[kWavetableSize];
     for (uint32_t i = threadIdx.x * 4u; i < kWavetableSize; i += kSynthThreads * 4u)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
             const int s = KIND == SOTS_SYNTH_TRIPLE_PAR ? (g & 3) : g;
             p[g] = sp.pmin[s] + values[(size_t)ind * D + g] * (sp.pmax[s] - sp.pmin[s]);
         }
-        float *__restrict__ out = audio + (size_t)ind * n;
+        float *__restrict__ out = audio + (size_t)ind * pitch;
 
         if constexpr (KIND == SOTS_SYNTH_2OP) {
             // Evolutionary_Strategy.hpp:372-401
@@ -344,16 +344,19 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
 // window (Evolutionary_Strategy.hpp:308-317) rounded once to fp32.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_window(float *__restrict__ audio, const float *__restrict__ window,
-                                                size_t total4, uint32_t n_mask4)
+                                                size_t total4, uint32_t log2n4, uint32_t pitch4)
 {
     float4 *a4 = reinterpret_cast<float4 *>(audio);
     const float4 *w4 = reinterpret_cast<const float4 *>(window);
+    const uint32_t mask = (1u << log2n4) - 1u;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
          e += (size_t)gridDim.x * blockDim.x) {
-        float4 v = a4[e];
-        const float4 w = w4[e & n_mask4];
+        const size_t row = e >> log2n4;
+        const uint32_t col = (uint32_t)e & mask;
+        float4 v = a4[row * pitch4 + col];
+        const float4 w = w4[col];
         v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
-        a4[e] = v;
+        a4[row * pitch4 + col] = v;
     }
 }
 
@@ -532,13 +535,13 @@ template <int LOG2N, int MODE>
 __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
                                                const float2 *__restrict__ tw, uint32_t p_len, float inv_n,
-                                               float inv_wf)
+                                               float inv_wf, uint32_t pitch)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave;
     __shared__ float2 lds[M + M / 8 + 1];
     const int lane = threadIdx.x;
     for (uint32_t ind = blockIdx.x; ind < p_len; ind += gridDim.x) {
-        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * N);
+        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * pitch);
         float2 x[E];
 #pragma unroll
         for (int s = 0; s < E; ++s) x[s] = in[lane + kWave * s];
@@ -787,36 +790,36 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 template <int KIND>
 static hipError_t launch_synth_kind(hipStream_t st, const float *values, const float *wavetable,
                                     const float *window, float *audio, const SynthParams &sp, uint32_t p,
-                                    uint32_t n, uint32_t grid)
+                                    uint32_t n, uint32_t pitch, uint32_t grid)
 {
     if (window)
-        k_synth<KIND, true><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n);
+        k_synth<KIND, true><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n, pitch);
     else
-        k_synth<KIND, false><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n);
+        k_synth<KIND, false><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n, pitch);
     return hipGetLastError();
 }
 
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         const float *window, float *audio, const SynthParams &sp, uint32_t p,
-                        uint32_t log2n, uint32_t num_cus)
+                        uint32_t log2n, uint32_t pitch, uint32_t num_cus)
 {
     const uint32_t n = 1u << log2n;
     // one 128 KiB-LDS workgroup per CU; further individuals are taken in a block-stride loop
     const uint32_t grid = grid_for(p, kSynthThreads, num_cus ? num_cus : 256);
     switch (kind) {
-    case SOTS_SYNTH_2OP: return launch_synth_kind<SOTS_SYNTH_2OP>(st, values, wavetable, window, audio, sp, p, n, grid);
-    case SOTS_SYNTH_3OP_SERIES: return launch_synth_kind<SOTS_SYNTH_3OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, grid);
-    case SOTS_SYNTH_TRIPLE_PAR: return launch_synth_kind<SOTS_SYNTH_TRIPLE_PAR>(st, values, wavetable, window, audio, sp, p, n, grid);
-    case SOTS_SYNTH_4OP_SERIES: return launch_synth_kind<SOTS_SYNTH_4OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, grid);
+    case SOTS_SYNTH_2OP: return launch_synth_kind<SOTS_SYNTH_2OP>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
+    case SOTS_SYNTH_3OP_SERIES: return launch_synth_kind<SOTS_SYNTH_3OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
+    case SOTS_SYNTH_TRIPLE_PAR: return launch_synth_kind<SOTS_SYNTH_TRIPLE_PAR>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
+    case SOTS_SYNTH_4OP_SERIES: return launch_synth_kind<SOTS_SYNTH_4OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n)
+hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n,
+                         uint32_t pitch)
 {
     const size_t total4 = ((size_t)p << log2n) / 4;
-    const uint32_t mask4 = ((1u << log2n) / 4) - 1;
-    k_window<<<grid_for(total4, 256, 8192), 256, 0, st>>>(audio, window, total4, mask4);
+    k_window<<<grid_for(total4, 256, 8192), 256, 0, st>>>(audio, window, total4, log2n - 2, pitch / 4);
     return hipGetLastError();
 }
 
@@ -838,10 +841,10 @@ static uint32_t wave_grid(uint32_t p, uint32_t num_cus)
 }
 
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
-                      uint32_t p, uint32_t log2n, uint32_t num_cus)
+                      uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus)
 {
     const uint32_t grid = wave_grid(p, num_cus);
-#define CALL(L) k_fft<L, 0><<<grid, kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, p, 0.f, 0.f)
+#define CALL(L) k_fft<L, 0><<<grid, kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, p, 0.f, 0.f, pitch)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
     return hipGetLastError();
@@ -858,11 +861,11 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
 }
 
 hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *target, float *fitness,
-                              const float2 *twiddle, uint32_t p, uint32_t log2n, float inv_n,
+                              const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch, float inv_n,
                               float inv_wf, uint32_t num_cus)
 {
     const uint32_t grid = wave_grid(p, num_cus);
-#define CALL(L) k_fft<L, 1><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, p, inv_n, inv_wf)
+#define CALL(L) k_fft<L, 1><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, p, inv_n, inv_wf, pitch)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
     return hipGetLastError();
