@@ -48,6 +48,7 @@ struct sots_ctx {
     float *wavetable = nullptr, *window = nullptr, *rows = nullptr;
     float2 *twiddle = nullptr;
     uint64_t *keys = nullptr;
+    void *sort_scratch = nullptr;
     uint32_t rows_capacity = 0;
     // host tables
     std::vector<double> window64;
@@ -172,7 +173,7 @@ void free_ctx(sots_ctx *ctx)
         for (auto &ev : ck.spare) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     }
     void *bufs[] = {ctx->values, ctx->steps, ctx->fitness, ctx->audio, ctx->spectrum, ctx->target,
-                    ctx->wavetable, ctx->window, ctx->rows, ctx->twiddle, ctx->keys};
+                    ctx->wavetable, ctx->window, ctx->rows, ctx->twiddle, ctx->keys, ctx->sort_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -298,6 +299,7 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     CREATE_HIP(hipMalloc((void **)&ctx->window, (size_t)ctx->N * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&ctx->twiddle, (size_t)ctx->N * sizeof(float2)));
     CREATE_HIP(hipMalloc((void **)&ctx->keys, (size_t)ctx->n_pad * sizeof(uint64_t)));
+    CREATE_HIP(hipMalloc(&ctx->sort_scratch, sort_scratch_bytes(ctx->P)));
     CREATE_HIP(hipMemsetAsync(ctx->values, 0, pd_bytes, ctx->stream));
     CREATE_HIP(hipMemsetAsync(ctx->steps, 0, pd_bytes, ctx->stream));
     CREATE_HIP(hipMemsetAsync(ctx->fitness, 0, (size_t)2 * ctx->P * sizeof(float), ctx->stream));
@@ -538,7 +540,7 @@ int sots_stage_sort(sots_ctx *ctx)
     {
         StageScope t(ctx, SOTS_STAGE_SORT);
         SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
-                                  ctx->fit(dst), ctx->keys, ctx->P, ctx->D));
+                                  ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D));
     }
     return maybe_drain(ctx);
 }
@@ -596,7 +598,7 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         {
             StageScope t(ctx, SOTS_STAGE_SORT);
             SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
-                                      ctx->fit(dst), ctx->keys, ctx->P, ctx->D));
+                                      ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D));
         }
         ctx->rot = dst;
         ctx->generation += 1;

@@ -68,9 +68,11 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *t
                               float inv_wf, uint32_t num_cus);
 
 // ---- selection ----
-// keys: P_pad 64-bit words of scratch (P_pad = next power of two >= P)
+// keys: P_pad 64-bit words (P_pad = next power of two >= P); scratch: sort_scratch_bytes(P) bytes
+size_t sort_scratch_bytes(uint32_t p);
 hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
-                       float *vout, float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d);
+                       float *vout, float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p,
+                       uint32_t d);
 
 // ---- island exchange ----
 hipError_t launch_pack_rows(hipStream_t st, const float *values, const float *steps, const float *fitness,

@@ -633,21 +633,24 @@ __device__ __forceinline__ void cmp_swap(uint64_t &a, uint64_t &b, bool ascendin
 // Builds the keys of one tile and sorts it completely (all steps with k <= tile).
 __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const float *__restrict__ fitness,
                                                              uint64_t *__restrict__ keys, uint32_t p_len,
-                                                             uint32_t tile)
+                                                             uint32_t tile, uint32_t alternate)
 {
     __shared__ uint64_t s[kSortTile];
     const uint32_t base = blockIdx.x * tile;
-    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) {
+    // alternate != 0: odd tiles end up descending, ready for further global bitonic merges;
+    // alternate == 0: every tile ascending (rank merge)
+    const uint32_t dir_base = alternate ? base : 0u;
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
         const uint32_t g = base + i;
         s[i] = g < p_len ? make_key(fitness[g], g) : ~0ull;
     }
     __syncthreads();
     for (uint32_t k = 2; k <= tile; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < tile / 2; t += kSortThreads) {
+            for (uint32_t t = threadIdx.x; t < tile / 2; t += blockDim.x) {
                 const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const uint32_t hi = lo | j;
-                const bool asc = (((base + lo) & k) == 0);
+                const bool asc = (((dir_base + lo) & k) == 0);
                 uint64_t a = s[lo], b = s[hi];
                 cmp_swap(a, b, asc);
                 s[lo] = a;
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const float *__rest
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) keys[base + i] = s[i];
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) keys[base + i] = s[i];
 }
 
 // One compare-exchange step (k, j) with j >= tile, over the whole padded array.
@@ -680,11 +683,11 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tile_merge(uint64_t *__re
 {
     __shared__ uint64_t s[kSortTile];
     const uint32_t base = blockIdx.x * tile;
-    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) s[i] = keys[base + i];
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) s[i] = keys[base + i];
     __syncthreads();
     const bool asc = ((base & k) == 0); // k > tile: the direction is uniform over the tile
     for (uint32_t j = tile >> 1; j > 0; j >>= 1) {
-        for (uint32_t t = threadIdx.x; t < tile / 2; t += kSortThreads) {
+        for (uint32_t t = threadIdx.x; t < tile / 2; t += blockDim.x) {
             const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
             const uint32_t hi = lo | j;
             uint64_t a = s[lo], b = s[hi];
@@ -694,7 +697,81 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tile_merge(uint64_t *__re
         }
         __syncthreads();
     }
-    for (uint32_t i = threadIdx.x; i < tile; i += kSortThreads) keys[base + i] = s[i];
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) keys[base + i] = s[i];
+}
+
+// ---- rank merge of sorted tiles ------------------------------------------------------
+// With T sorted tiles of unique keys, the final position of a key is the number of keys
+// below it = its index in its own tile + sum over the other tiles of lower_bound(tile, key).
+// Workgroup (a, b) stages tile b in LDS and binary-searches every key of tile a in it;
+// the T partial counts per key are then summed by the scatter kernel, which moves the
+// (2D+1)-float row straight to its final place.  Two launches instead of the ~15 of the
+// global bitonic steps, and every CU is busy.
+constexpr int kRankThreads = 256;
+
+__global__ __launch_bounds__(kRankThreads) void k_sort_rank_pairs(const uint64_t *__restrict__ keys,
+                                                                  uint16_t *__restrict__ partial,
+                                                                  uint32_t n_pad, uint32_t tile)
+{
+    __shared__ uint64_t s[kSortTile];
+    const uint32_t a = blockIdx.x, b = blockIdx.y;
+    uint16_t *__restrict__ out = partial + (size_t)b * n_pad + (size_t)a * tile;
+    if (a == b) { // own tile: the sorted index is the count
+        for (uint32_t i = threadIdx.x; i < tile; i += kRankThreads) out[i] = (uint16_t)i;
+        return;
+    }
+    const uint64_t *__restrict__ kb = keys + (size_t)b * tile;
+    for (uint32_t i = threadIdx.x; i < tile; i += kRankThreads) s[i] = kb[i];
+    __syncthreads();
+    const uint64_t *__restrict__ ka = keys + (size_t)a * tile;
+    for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 4 * kRankThreads) {
+        uint64_t x[4];
+        uint32_t pos[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + q * kRankThreads;
+            x[q] = i < tile ? ka[i] : 0ull;
+            pos[q] = 0;
+        }
+        for (uint32_t step = tile >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pos[q] += (s[pos[q] + step - 1] < x[q]) ? step : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + q * kRankThreads;
+            if (i < tile) out[i] = (uint16_t)(pos[q] + ((s[pos[q]] < x[q]) ? 1u : 0u));
+        }
+    }
+}
+
+// Sums the T partial counts of 256 consecutive sorted-tile slots and scatters their rows.
+__global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64_t *__restrict__ keys,
+                                                                    const uint16_t *__restrict__ partial,
+                                                                    const float *__restrict__ vin,
+                                                                    const float *__restrict__ sin,
+                                                                    const float *__restrict__ fin,
+                                                                    float *__restrict__ vout, float *__restrict__ sout,
+                                                                    float *__restrict__ fout, uint32_t n_pad,
+                                                                    uint32_t tiles, uint32_t p_len, uint32_t d)
+{
+    __shared__ uint32_t dst_row[kRankThreads];
+    __shared__ uint32_t src_row[kRankThreads];
+    const uint32_t e = blockIdx.x * kRankThreads + threadIdx.x; // slot in the tile-sorted key array
+    uint32_t rank = 0;
+    for (uint32_t b = 0; b < tiles; ++b) rank += partial[(size_t)b * n_pad + e];
+    dst_row[threadIdx.x] = rank;
+    src_row[threadIdx.x] = (uint32_t)keys[e]; // 0xffffffff for padding keys
+    __syncthreads();
+    const uint32_t w = 2 * d + 1;
+    for (uint32_t t = threadIdx.x; t < kRankThreads * w; t += kRankThreads) {
+        const uint32_t j = t / w, c = t - j * w;
+        const uint32_t src = src_row[j], dst = dst_row[j];
+        if (src >= p_len) continue;
+        if (c < d) vout[(size_t)dst * d + c] = vin[(size_t)src * d + c];
+        else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = sin[(size_t)src * d + (c - d)];
+        else fout[dst] = fin[src];
+    }
 }
 
 // Row r of the new half <- row (keys[r] & 0xffffffff) of the old half.
@@ -871,17 +948,51 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *t
     return hipGetLastError();
 }
 
-hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
-                       float *vout, float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d)
+// Tile size and count of the rank-merge sort for a padded length, or tiles == 1 when one LDS
+// tile holds everything.  tiles > kSortMaxTiles falls back to global bitonic steps.
+constexpr uint32_t kSortMaxTiles = 256;
+
+static void sort_plan(uint32_t n_pad, uint32_t &tile, uint32_t &tiles)
+{
+    if (n_pad <= kSortTile) {
+        tile = n_pad;
+    } else {
+        tile = n_pad <= 131072u ? 1024u : kSortTile;
+    }
+    tiles = n_pad / tile;
+}
+
+size_t sort_scratch_bytes(uint32_t p)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
-    const uint32_t tile = n_pad < kSortTile ? n_pad : kSortTile;
-    const uint32_t tiles = n_pad / tile;
-    k_sort_tiles<<<tiles, kSortThreads, 0, st>>>(fin, keys, p, tile);
+    uint32_t tile, tiles;
+    sort_plan(n_pad, tile, tiles);
+    if (tiles <= 1 || tiles > kSortMaxTiles) return 16;
+    return (size_t)tiles * n_pad * sizeof(uint16_t);
+}
+
+hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
+                       float *vout, float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p,
+                       uint32_t d)
+{
+    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    uint32_t tile, tiles;
+    sort_plan(n_pad, tile, tiles);
+    uint32_t threads = tile / 2;
+    threads = threads < 64 ? 64 : threads > (uint32_t)kSortThreads ? (uint32_t)kSortThreads : threads;
+    const bool rank_merge = tiles > 1 && tiles <= kSortMaxTiles;
+    k_sort_tiles<<<tiles, threads, 0, st>>>(fin, keys, p, tile, rank_merge ? 0u : 1u);
+    if (rank_merge) {
+        uint16_t *partial = static_cast<uint16_t *>(scratch);
+        k_sort_rank_pairs<<<dim3(tiles, tiles), kRankThreads, 0, st>>>(keys, partial, n_pad, tile);
+        k_sort_rank_scatter<<<n_pad / kRankThreads, kRankThreads, 0, st>>>(keys, partial, vin, sin, fin, vout, sout,
+                                                                          fout, n_pad, tiles, p, d);
+        return hipGetLastError();
+    }
     for (uint32_t k = tile << 1; k <= n_pad && k != 0; k <<= 1) {
         for (uint32_t j = k >> 1; j >= tile; j >>= 1)
             k_sort_global_step<<<grid_for(n_pad / 2, 256), 256, 0, st>>>(keys, n_pad, k, j);
-        k_sort_tile_merge<<<tiles, kSortThreads, 0, st>>>(keys, k, tile);
+        k_sort_tile_merge<<<tiles, threads, 0, st>>>(keys, k, tile);
     }
     k_sort_gather<<<grid_for((uint64_t)p * (2 * d + 1), 256), 256, 0, st>>>(keys, vin, sin, fin, vout, sout,
                                                                             fout, p, d);
