@@ -708,44 +708,57 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tile_merge(uint64_t *__re
 // (2D+1)-float row straight to its final place.  Two launches instead of the ~15 of the
 // global bitonic steps, and every CU is busy.
 constexpr int kRankThreads = 256;
+constexpr uint32_t kRankGroup = 8;      // tiles staged in LDS per workgroup (tile = 1024: 64 KiB)
+constexpr uint32_t kRankLdsKeys = 8192; // LDS capacity in keys
 
+// Workgroup (a, g): keys of tile a against tiles [g*group, (g+1)*group); writes one partial
+// count per key of a.  Against its own tile a key's count is its sorted index.
 __global__ __launch_bounds__(kRankThreads) void k_sort_rank_pairs(const uint64_t *__restrict__ keys,
                                                                   uint16_t *__restrict__ partial,
-                                                                  uint32_t n_pad, uint32_t tile)
+                                                                  uint32_t n_pad, uint32_t tile, uint32_t group)
 {
-    __shared__ uint64_t s[kSortTile];
-    const uint32_t a = blockIdx.x, b = blockIdx.y;
-    uint16_t *__restrict__ out = partial + (size_t)b * n_pad + (size_t)a * tile;
-    if (a == b) { // own tile: the sorted index is the count
-        for (uint32_t i = threadIdx.x; i < tile; i += kRankThreads) out[i] = (uint16_t)i;
-        return;
-    }
-    const uint64_t *__restrict__ kb = keys + (size_t)b * tile;
-    for (uint32_t i = threadIdx.x; i < tile; i += kRankThreads) s[i] = kb[i];
+    __shared__ uint64_t s[kRankLdsKeys];
+    const uint32_t a = blockIdx.x, g = blockIdx.y;
+    const uint32_t b0 = g * group;
+    const uint64_t *__restrict__ kb = keys + (size_t)b0 * tile;
+    for (uint32_t i = threadIdx.x; i < group * tile; i += kRankThreads) s[i] = kb[i];
     __syncthreads();
     const uint64_t *__restrict__ ka = keys + (size_t)a * tile;
+    uint16_t *__restrict__ out = partial + (size_t)g * n_pad + (size_t)a * tile;
     for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 4 * kRankThreads) {
         uint64_t x[4];
-        uint32_t pos[4];
+        uint32_t total[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t i = i0 + q * kRankThreads;
             x[q] = i < tile ? ka[i] : 0ull;
-            pos[q] = 0;
+            total[q] = 0;
         }
-        for (uint32_t step = tile >> 1; step >= 1; step >>= 1) {
+        for (uint32_t bb = 0; bb < group; ++bb) {
+            const uint64_t *__restrict__ sb = s + bb * tile;
+            if (b0 + bb == a) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pos[q] += (s[pos[q] + step - 1] < x[q]) ? step : 0u;
+                for (int q = 0; q < 4; ++q) total[q] += i0 + q * kRankThreads;
+                continue;
+            }
+            uint32_t pos[4] = {0, 0, 0, 0};
+            for (uint32_t step = tile >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pos[q] += (sb[pos[q] + step - 1] < x[q]) ? step : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) total[q] += pos[q] + ((sb[pos[q]] < x[q]) ? 1u : 0u);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t i = i0 + q * kRankThreads;
-            if (i < tile) out[i] = (uint16_t)(pos[q] + ((s[pos[q]] < x[q]) ? 1u : 0u));
+            if (i < tile) out[i] = (uint16_t)total[q];
         }
     }
 }
 
-// Sums the T partial counts of 256 consecutive sorted-tile slots and scatters their rows.
+// 64 consecutive slots of the tile-sorted key array per workgroup: four quarter-sums of the
+// partial counts per slot (all 256 lanes load), then the rows move to their final places.
 __global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64_t *__restrict__ keys,
                                                                     const uint16_t *__restrict__ partial,
                                                                     const float *__restrict__ vin,
@@ -753,21 +766,24 @@ __global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64
                                                                     const float *__restrict__ fin,
                                                                     float *__restrict__ vout, float *__restrict__ sout,
                                                                     float *__restrict__ fout, uint32_t n_pad,
-                                                                    uint32_t tiles, uint32_t p_len, uint32_t d)
+                                                                    uint32_t groups, uint32_t p_len, uint32_t d)
 {
-    __shared__ uint32_t dst_row[kRankThreads];
-    __shared__ uint32_t src_row[kRankThreads];
-    const uint32_t e = blockIdx.x * kRankThreads + threadIdx.x; // slot in the tile-sorted key array
-    uint32_t rank = 0;
-    for (uint32_t b = 0; b < tiles; ++b) rank += partial[(size_t)b * n_pad + e];
-    dst_row[threadIdx.x] = rank;
-    src_row[threadIdx.x] = (uint32_t)keys[e]; // 0xffffffff for padding keys
+    constexpr uint32_t kSlots = 64;
+    __shared__ uint32_t part[4][kSlots];
+    __shared__ uint32_t src_row[kSlots];
+    const uint32_t j = threadIdx.x & (kSlots - 1), quarter = threadIdx.x / kSlots;
+    const uint32_t e = blockIdx.x * kSlots + j;
+    uint32_t sum = 0;
+    for (uint32_t g = quarter; g < groups; g += 4) sum += partial[(size_t)g * n_pad + e];
+    part[quarter][j] = sum;
+    if (quarter == 0) src_row[j] = (uint32_t)keys[e]; // 0xffffffff for padding keys
     __syncthreads();
     const uint32_t w = 2 * d + 1;
-    for (uint32_t t = threadIdx.x; t < kRankThreads * w; t += kRankThreads) {
-        const uint32_t j = t / w, c = t - j * w;
-        const uint32_t src = src_row[j], dst = dst_row[j];
+    for (uint32_t t = threadIdx.x; t < kSlots * w; t += kRankThreads) {
+        const uint32_t jj = t / w, c = t - jj * w;
+        const uint32_t src = src_row[jj];
         if (src >= p_len) continue;
+        const uint32_t dst = part[0][jj] + part[1][jj] + part[2][jj] + part[3][jj];
         if (c < d) vout[(size_t)dst * d + c] = vin[(size_t)src * d + c];
         else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = sin[(size_t)src * d + (c - d)];
         else fout[dst] = fin[src];
@@ -962,13 +978,24 @@ static void sort_plan(uint32_t n_pad, uint32_t &tile, uint32_t &tiles)
     tiles = n_pad / tile;
 }
 
+// tiles staged per rank workgroup: as many as fit the LDS buffer and a 16-bit count
+static uint32_t rank_group(uint32_t tile, uint32_t tiles)
+{
+    uint32_t group = kRankLdsKeys / tile;
+    if (group > kRankGroup) group = kRankGroup;
+    if (group < 1) group = 1;
+    while (group > tiles) group >>= 1;
+    return group;
+}
+
 size_t sort_scratch_bytes(uint32_t p)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
     uint32_t tile, tiles;
     sort_plan(n_pad, tile, tiles);
     if (tiles <= 1 || tiles > kSortMaxTiles) return 16;
-    return (size_t)tiles * n_pad * sizeof(uint16_t);
+    const uint32_t group = rank_group(tile, tiles);
+    return (size_t)(tiles / group) * n_pad * sizeof(uint16_t);
 }
 
 hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
@@ -984,9 +1011,10 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
     k_sort_tiles<<<tiles, threads, 0, st>>>(fin, keys, p, tile, rank_merge ? 0u : 1u);
     if (rank_merge) {
         uint16_t *partial = static_cast<uint16_t *>(scratch);
-        k_sort_rank_pairs<<<dim3(tiles, tiles), kRankThreads, 0, st>>>(keys, partial, n_pad, tile);
-        k_sort_rank_scatter<<<n_pad / kRankThreads, kRankThreads, 0, st>>>(keys, partial, vin, sin, fin, vout, sout,
-                                                                          fout, n_pad, tiles, p, d);
+        const uint32_t group = rank_group(tile, tiles), groups = tiles / group;
+        k_sort_rank_pairs<<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile, group);
+        k_sort_rank_scatter<<<n_pad / 64, kRankThreads, 0, st>>>(keys, partial, vin, sin, fin, vout, sout, fout,
+                                                               n_pad, groups, p, d);
         return hipGetLastError();
     }
     for (uint32_t k = tile << 1; k <= n_pad && k != 0; k <<= 1) {
