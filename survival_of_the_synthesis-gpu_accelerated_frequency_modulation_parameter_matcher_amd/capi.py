@@ -80,11 +80,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SOTS_LIB_PATH", LIB_PATH)  # development override (kernel variants)
+    if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C <package dir>`; there is no CPU fallback")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     L.sots_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.sots_destroy.argtypes = [vp]

@@ -371,6 +371,10 @@ __global__ __launch_bounds__(256) void k_window(float *__restrict__ audio, const
 // buffer between passes.  A final split step turns Z[k], Z[M-k] into the real-input bins
 // X[k], X[M-k].
 // ------------------------------------------------------------------------------------
+// The transform is not bit-matched to anything (the oracle's FFT is fp64), so fused
+// multiply-adds are allowed here and only here; "on" contracts within one expression, which
+// keeps k_fft<.,1> and k_fitness on identical arithmetic.
+#pragma clang fp contract(on)
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
@@ -487,91 +491,139 @@ __device__ __forceinline__ void fft_forward(float2 (&x)[M / kWave], float2 *__re
 #undef SOTS_NEXT
 }
 
-// Real-input split for the pair (k, M-k), 0 < k < M/2:
+// Real-input split for the pair (k, M-k), 0 <= k < M/2, from Z in LDS:
 //   Ee = (Z[k] + conj Z[M-k]) / 2,  Oo = -i (Z[k] - conj Z[M-k]) / 2,  T = e^{-2 pi i k/N} Oo
 //   X[k] = Ee + T,  X[M-k] = conj(Ee - T)
-// k == 0 pairs bin 0 with bin M/2 instead: X[0] = Re Z0 + Im Z0, X[M/2] = conj Z[M/2];
-// the Nyquist bin X[M] = Re Z0 - Im Z0 is returned separately.
+// With Z[M] read as Z[0] the same formula gives X[0] = Re Z0 + Im Z0 and the Nyquist bin
+// X[M] = Re Z0 - Im Z0 for k = 0, so no lane takes a different path.  Bin M/2, which no pair
+// covers, is X[M/2] = conj Z[M/2].
 template <int M>
-__device__ __forceinline__ void split_pair(const float2 *__restrict__ lds, const float2 *__restrict__ tw,
-                                           int k, float2 &xa, float2 &xb, float2 &nyq)
+__device__ __forceinline__ void split_pair(const float2 *__restrict__ lds, float2 w, int k, float2 &xa, float2 &xb)
 {
-    if (k == 0) {
-        const float2 z0 = lds[lds_pad(0)], zh = lds[lds_pad(M / 2)];
-        xa = make_float2(z0.x + z0.y, 0.0f);
-        xb = make_float2(zh.x, -zh.y);
-        nyq = make_float2(z0.x - z0.y, 0.0f);
-    } else {
-        const float2 a = lds[lds_pad(k)], bz = lds[lds_pad(M - k)];
-        const float2 b = make_float2(bz.x, -bz.y);
-        const float2 ee = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-        const float2 dd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-        const float2 oo = make_float2(dd.y, -dd.x);
-        const float2 t = cmul(oo, tw[k]);
-        xa = cadd(ee, t);
-        const float2 d2 = csub(ee, t);
-        xb = make_float2(d2.x, -d2.y);
-    }
+    const float2 a = lds[lds_pad(k)], bz = lds[lds_pad((M - k) & (M - 1))];
+    const float2 b = make_float2(bz.x, -bz.y);
+    const float2 ee = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    const float2 dd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float2 oo = make_float2(dd.y, -dd.x);
+    const float2 t = cmul(oo, w);
+    xa = cadd(ee, t);
+    const float2 d2 = csub(ee, t);
+    xb = make_float2(d2.x, -d2.y);
 }
 
-// |X| / N / windowFactor, Evolutionary_Strategy.hpp:517-519 / ocl_program.cl:608-611
+// |X| / N / windowFactor, Evolutionary_Strategy.hpp:517-519 / ocl_program.cl:608-611.
+// v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: the transform feeding it is
+// fp32 against the oracle's fp64 anyway.
 __device__ __forceinline__ float bin_error(float2 x, float target, float inv_n, float inv_wf)
 {
-    const float raw = sqrtf(x.x * x.x + x.y * x.y);
+    const float raw = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
     const float mag = raw * inv_n * inv_wf;
     const float e = mag - target;
     return e * e;
 }
 
+// Wavefront sum without LDS traffic: DPP swaps inside each row of 16 lanes (every lane of a
+// row ends with the row total), then the four row totals are added in row order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(m);
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v); // row_half_mirror
+    v = dpp_add<0x140>(v); // row_mirror
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return ((r0 + r1) + r2) + r3;
 }
 
 // MODE 0: write spectrum rows; MODE 1: accumulate the fitness directly
+#ifndef SOTS_FFT_MIN_WAVES
+#define SOTS_FFT_MIN_WAVES 1
+#endif
 template <int LOG2N, int MODE>
-__global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
+__global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
                                                const float2 *__restrict__ tw, uint32_t p_len, float inv_n,
                                                float inv_wf, uint32_t pitch)
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave;
+    constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave, H = E / 2;
     __shared__ float2 lds[M + M / 8 + 1];
     const int lane = threadIdx.x;
-    for (uint32_t ind = blockIdx.x; ind < p_len; ind += gridDim.x) {
+    uint32_t ind = blockIdx.x;
+    if (ind >= p_len) return;
+
+    // per-lane constants of the split / fitness step, loaded once (nothing but the audio
+    // prefetch is in flight inside the loop, so its waits never drain the prefetch)
+    float2 w_split[H];
+    float tgt_a[H], tgt_b[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+        const int k = lane + kWave * q;
+        w_split[q] = tw[k];
+        if constexpr (MODE == 1) {
+            tgt_a[q] = target[k];
+            tgt_b[q] = target[k == 0 ? M / 2 : M - k];
+        }
+    }
+
+    float2 x[E];
+    {
         const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * pitch);
-        float2 x[E];
 #pragma unroll
         for (int s = 0; s < E; ++s) x[s] = in[lane + kWave * s];
+    }
+    while (true) {
+        // the next individual's row is requested before this one is transformed, so its HBM
+        // latency hides behind the passes below
+        const uint32_t nxt = ind + gridDim.x;
+        const bool more = nxt < p_len;
+        float2 y[E];
+        {
+            const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : ind) * pitch);
+#pragma unroll
+            for (int s = 0; s < E; ++s) y[s] = in[lane + kWave * s];
+        }
         fft_forward<M>(x, lds, tw, lane);
+        const float2 zh = lds[lds_pad(M / 2)];
+        const float2 x_half = make_float2(zh.x, -zh.y); // bin M/2
         if constexpr (MODE == 0) {
             float2 *__restrict__ row = reinterpret_cast<float2 *>(spectrum + (size_t)ind * (N + 8));
 #pragma unroll
-            for (int q = 0; q < E / 2; ++q) {
+            for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
-                float2 xa, xb, nyq;
-                split_pair<M>(lds, tw, k, xa, xb, nyq);
+                float2 xa, xb;
+                split_pair<M>(lds, w_split[q], k, xa, xb);
                 row[k] = xa;
-                row[k == 0 ? M / 2 : M - k] = xb;
-                if (k == 0) row[M] = nyq;
+                row[M - k] = xb; // k = 0 lands on the Nyquist bin M
             }
+            if (lane == 0) row[M / 2] = x_half;
         } else {
             float acc = 0.0f;
 #pragma unroll
-            for (int q = 0; q < E / 2; ++q) {
+            for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
-                float2 xa, xb, nyq;
-                split_pair<M>(lds, tw, k, xa, xb, nyq);
-                const int kb = k == 0 ? M / 2 : M - k;
-                acc += bin_error(xa, target[k], inv_n, inv_wf);
-                acc += bin_error(xb, target[kb], inv_n, inv_wf);
+                float2 xa, xb;
+                split_pair<M>(lds, w_split[q], k, xa, xb);
+                if (k == 0) xb = x_half; // the fitness skips the Nyquist bin and needs bin M/2
+                acc += bin_error(xa, tgt_a[q], inv_n, inv_wf);
+                acc += bin_error(xb, tgt_b[q], inv_n, inv_wf);
             }
             acc = wave_sum(acc);
             if (lane == 0) fitness[ind] = acc;
         }
+        if (!more) break;
         __syncthreads();
+#pragma unroll
+        for (int s = 0; s < E; ++s) x[s] = y[s];
+        ind = nxt;
     }
 }
 
@@ -599,6 +651,8 @@ __global__ __launch_bounds__(kWave) void k_fitness(const float *__restrict__ spe
         if (lane == 0) fitness[ind] = acc;
     }
 }
+
+#pragma clang fp contract(off)
 
 // ------------------------------------------------------------------------------------
 // sortPopulation, ocl_program.cl:664-711 (rank sort) / Population::bubbleSortPopulation,
@@ -929,7 +983,7 @@ hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint
 static uint32_t wave_grid(uint32_t p, uint32_t num_cus)
 {
     // one wavefront per individual; enough workgroups to fill every CU several times over
-    const uint32_t cap = (num_cus ? num_cus : 256) * 32;
+    const uint32_t cap = (num_cus ? num_cus : 256) * 16;
     return p < cap ? p : cap;
 }
 
