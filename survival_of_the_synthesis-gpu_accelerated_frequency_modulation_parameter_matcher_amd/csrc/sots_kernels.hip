@@ -191,21 +191,50 @@ __device__ __forceinline__ float tab_at(const float *tab, float pos)
 {
     int i = (int)pos; // == (unsigned)pos for every in-range phase
     i = min(max(i, 0), (int)kWavetableSize - 1);
+#ifdef SOTS_ABLATE_GATHER
+    return __int_as_float(i); // timing experiment only: no LDS read
+#else
     return tab[i];
+#endif
 }
 __device__ __forceinline__ void wrap_hi(float &p) { if (p >= kWf) p -= kWf; }
 __device__ __forceinline__ void wrap_lo(float &p) { if (p < 0.0f) p += kWf; }
 
+// The window value of sample i is the same for every lane (lane = individual), so it does
+// not need a memory access per sample: lane l keeps window[64*chunk + l] for the current
+// 64-sample chunk in one register and sample i reads it with v_readlane(i & 63).  (Scalar
+// loads per block cost ~15 % of the kernel: with one wavefront per SIMD nothing hides them.)
 template <bool WINDOW>
 __device__ __forceinline__ void store_block(float *__restrict__ out, const float (&y)[kSynthUnroll],
-                                            const float *__restrict__ window, uint32_t i)
+                                            float w_chunk, uint32_t i, bool active)
 {
     float v[kSynthUnroll];
+#if defined(SOTS_ABLATE_WINDOW)
 #pragma unroll
-    for (int u = 0; u < kSynthUnroll; ++u) v[u] = WINDOW ? y[u] * window[i + u] : y[u];
+    for (int u = 0; u < kSynthUnroll; ++u) v[u] = y[u];
+#else
 #pragma unroll
-    for (int u = 0; u < kSynthUnroll; u += 4)
-        *reinterpret_cast<float4 *>(out + i + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+    for (int u = 0; u < kSynthUnroll; ++u) {
+        if constexpr (WINDOW) {
+            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w_chunk), (int)((i + u) & (kWave - 1))));
+            v[u] = y[u] * w;
+        } else {
+            v[u] = y[u];
+        }
+    }
+#endif
+#ifdef SOTS_ABLATE_STORE
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < kSynthUnroll; ++u) acc += v[u];
+    if (acc == 123.456f) out[i] = acc; // timing experiment only: keeps the work alive, never stores
+#else
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < kSynthUnroll; u += 4)
+            *reinterpret_cast<float4 *>(out + i + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+    }
+#endif
 }
 
 template <int KIND, bool WINDOW>
@@ -226,8 +255,10 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
 
     for (uint32_t base = blockIdx.x * kSynthThreads; base < p_len; base += gridDim.x * kSynthThreads) {
-        const uint32_t ind = base + threadIdx.x;
-        if (ind >= p_len) continue;
+        // Every lane stays active (the window register is read across lanes): lanes past the
+        // end redo the last individual and never store.
+        const bool active = base + threadIdx.x < p_len;
+        const uint32_t ind = active ? base + threadIdx.x : p_len - 1u;
         float p[D];
 #pragma unroll
         for (int g = 0; g < D; ++g) {
@@ -238,18 +269,34 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
         }
         float *__restrict__ out = audio + (size_t)ind * pitch;
 
+        const int lane = threadIdx.x & (kWave - 1);
         if constexpr (KIND == SOTS_SYNTH_2OP) {
-            // Evolutionary_Strategy.hpp:372-401
+            // Evolutionary_Strategy.hpp:372-401, as a three-stage software pipeline over blocks of
+            // 8 samples so that no table read is waited for in the phase that issues it:
+            //   stage A (block b+1): modulator phase chain, issues its 8 table reads
+            //   stage B (block b)  : carrier phase chain from A's values, issues the 8 output reads
+            //   stage C (block b-1): amplitude, window, 16-byte stores
+            // Same arithmetic in the same per-sample order as the serial loop.
             const float mod = p[0] * p[1], fc = p[2], amp = p[3];
             const float inc1 = c * p[0];
             float pos1 = 0.0f, pos2 = 0.0f;
-            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
-                float t1[kSynthUnroll], y[kSynthUnroll];
+            float t1[kSynthUnroll], t1n[kSynthUnroll], y[kSynthUnroll], yp[kSynthUnroll];
+            float w_cur = 0.0f, w_next = 0.0f;
+            if constexpr (WINDOW) w_next = window[lane];
 #pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u) {
-                    t1[u] = tab_at(tab, pos1);
-                    pos1 += inc1;
-                    wrap_hi(pos1);
+            for (int u = 0; u < kSynthUnroll; ++u) {
+                t1[u] = tab_at(tab, pos1);
+                pos1 += inc1;
+                wrap_hi(pos1);
+            }
+            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
+                if (i + kSynthUnroll < n) {
+#pragma unroll
+                    for (int u = 0; u < kSynthUnroll; ++u) {
+                        t1n[u] = tab_at(tab, pos1);
+                        pos1 += inc1;
+                        wrap_hi(pos1);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u) {
@@ -259,9 +306,32 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                     wrap_hi(pos2);
                     wrap_lo(pos2);
                 }
+                if (i > 0) {
+                    const uint32_t ip = i - kSynthUnroll;
+                    if constexpr (WINDOW) {
+                        if ((ip & (kWave - 1)) == 0) { // entering a new 64-sample chunk
+                            w_cur = w_next;
+                            if (ip + kWave < n) w_next = window[ip + kWave + lane];
+                        }
+                    }
 #pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u) y[u] = y[u] * amp;
-                store_block<WINDOW>(out, y, window, i);
+                    for (int u = 0; u < kSynthUnroll; ++u) yp[u] = yp[u] * amp;
+                    store_block<WINDOW>(out, yp, w_cur, ip, active);
+                }
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u) {
+                    t1[u] = t1n[u];
+                    yp[u] = y[u];
+                }
+            }
+            {
+                const uint32_t ip = n - kSynthUnroll;
+                if constexpr (WINDOW) {
+                    if ((ip & (kWave - 1)) == 0) w_cur = w_next;
+                }
+#pragma unroll
+                for (int u = 0; u < kSynthUnroll; ++u) yp[u] = yp[u] * amp;
+                store_block<WINDOW>(out, yp, w_cur, ip, active);
             }
         } else if constexpr (KIND == SOTS_SYNTH_3OP_SERIES || KIND == SOTS_SYNTH_4OP_SERIES) {
             // Evolutionary_Strategy.hpp:407-445; the 4-op voice adds one more modulator stage
@@ -273,7 +343,11 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
             float pos[OPS];
 #pragma unroll
             for (int o = 0; o < OPS; ++o) pos[o] = 0.0f;
+            float w_cur = 0.0f;
             for (uint32_t i = 0; i < n; i += kSynthUnroll) {
+                if constexpr (WINDOW) {
+                    if ((i & (kWave - 1)) == 0) w_cur = window[i + lane];
+                }
                 float t[kSynthUnroll], y[kSynthUnroll];
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u) {
@@ -296,7 +370,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                 }
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u) y[u] = t[u] * m[OPS - 1];
-                store_block<WINDOW>(out, y, window, i);
+                store_block<WINDOW>(out, y, w_cur, i, active);
             }
         } else {
             // Evolutionary_Strategy.hpp:457-494
@@ -310,7 +384,11 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                 pa[j] = 0.0f;
                 pb[j] = 0.0f;
             }
+            float w_cur = 0.0f;
             for (uint32_t i = 0; i < n; i += kSynthUnroll) {
+                if constexpr (WINDOW) {
+                    if ((i & (kWave - 1)) == 0) w_cur = window[i + lane];
+                }
                 float tot[3][kSynthUnroll], y[kSynthUnroll];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -333,7 +411,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u)
                     y[u] = (tot[0][u] + tot[1][u] + tot[2][u]) / 3.0f; // == (float)(double(sum)/3.0), :493
-                store_block<WINDOW>(out, y, window, i);
+                store_block<WINDOW>(out, y, w_cur, i, active);
             }
         }
     }
