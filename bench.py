@@ -140,10 +140,10 @@ def main():
     kernels = {}
     for name, stage, alg_bytes in (
             ("recombine+mutate", c.STAGE_FUSED_VARIATION, 16 * es.D),
-            # synth write 4N + window read/write 8N
-            ("synthesise+window", c.STAGE_FUSED_SYNTH, 12 * N),
-            # FFT read 4N + write 8(N/2+1), fitness read 8(N/2+1)
-            ("FFT+fitness", c.STAGE_FUSED_SPECTRAL, 12 * N + 16),
+            # SURVEY 8(d) shares of B_alg = 24N+16: synth write 4N
+            ("synthesise", c.STAGE_FUSED_SYNTH, 4 * N),
+            # window read/write 8N + FFT read 4N + write 8(N/2+1) + fitness read 8(N/2+1)
+            ("window+FFT+fitness", c.STAGE_FUSED_SPECTRAL, 20 * N + 16),
             ("sortPopulation", c.STAGE_SORT, 16 + 8 * (2 * es.D + 1))):
         ms, cnt = es.stage_time_ms(stage)
         if cnt:
@@ -188,8 +188,8 @@ def main():
             "pipeline_effective": {"b_alg_bytes_per_candidate": b_alg,
                                    "effective_GBs_per_gpu": value / world * b_alg / 1e9,
                                    "frac_of_hbm_peak": value / world * b_alg / 1e9 / HBM_PEAK_GBS,
-                                   "note": "window fused into synth and the spectrum never materialised: the loop moves "
-                                           "8N bytes per candidate, not B_alg = 24N+16, so this is an effective figure"},
+                                   "note": "window applied on the FFT kernel's load and the spectrum never materialised: the loop "
+                                           "moves 8N bytes per candidate, not B_alg = 24N+16, so this is an effective figure"},
             "kernels": kernels,
             "best_fitness_sse": best,
             "best_fitness_mse": best / (N // 2),

@@ -65,8 +65,8 @@ enum sots_stage {
     SOTS_STAGE_ROTATE = 8,
     /* kernels of the fused generation loop (sots_execute_generations) */
     SOTS_STAGE_FUSED_VARIATION = 9, /* recombine + mutate */
-    SOTS_STAGE_FUSED_SYNTH = 10,    /* synthesise + window */
-    SOTS_STAGE_FUSED_SPECTRAL = 11, /* FFT + fitness */
+    SOTS_STAGE_FUSED_SYNTH = 10,    /* synthesise */
+    SOTS_STAGE_FUSED_SPECTRAL = 11, /* window + FFT + fitness */
     SOTS_STAGE_COUNT = 12
 };
 
@@ -140,8 +140,10 @@ int sots_stage_rotate(sots_ctx *ctx);
 
 /* stage-separated generation: the eight stages above in reference order */
 int sots_execute_generation(sots_ctx *ctx);
-/* n generations of the fused loop (recombine+mutate | synth+window | FFT+fitness |
- * sort | rotate); same population results as n x sots_execute_generation.
+/* n generations of the fused loop (recombine+mutate | synthesise | window+FFT+fitness |
+ * sort | rotate); bit-identical population results to n x sots_execute_generation.
+ * The window is applied as the FFT kernel loads a row, so afterwards the audio buffer holds
+ * the UN-windowed synthesis and the spectrum buffer is untouched.
  * (executeAllGenerations, ...OpenCL.hpp:542-547) */
 int sots_execute_generations(sots_ctx *ctx, uint32_t n);
 

@@ -585,12 +585,13 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         ctx->rot = dst;
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH);
-            SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, ctx->window,
+            // raw synthesis: the window is applied by the FFT kernel as it loads the row
+            SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, nullptr,
                                        ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
         }
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL);
-            SOTS_HIP(ctx, launch_fft_fitness(ctx->stream, ctx->audio, ctx->target, ctx->fit(ctx->rot), ctx->twiddle, ctx->P,
+            SOTS_HIP(ctx, launch_fft_fitness(ctx->stream, ctx->audio, ctx->window, ctx->target, ctx->fit(ctx->rot), ctx->twiddle, ctx->P,
                                              ctx->log2n, ctx->pitch, ctx->inv_n, ctx->inv_wf, ctx->num_cus));
         }
         src = ctx->rot;

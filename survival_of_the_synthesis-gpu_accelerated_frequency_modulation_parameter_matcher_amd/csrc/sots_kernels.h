@@ -62,10 +62,10 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
 // spectrum[P][N+8] x target[N/2] -> fitness[P]
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus);
-// audio[P][N] x target -> fitness[P] without materialising the spectrum
-hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *target, float *fitness,
-                              const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch, float inv_n,
-                              float inv_wf, uint32_t num_cus);
+// audio[P][pitch] (x window when window != nullptr) x target -> fitness[P]; no spectrum in memory
+hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *window, const float *target,
+                              float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
+                              float inv_n, float inv_wf, uint32_t num_cus);
 
 // ---- selection ----
 // keys: P_pad 64-bit words (P_pad = next power of two >= P); scratch: sort_scratch_bytes(P) bytes

@@ -626,11 +626,14 @@ __device__ __forceinline__ float wave_sum(float v)
 #ifndef SOTS_FFT_MIN_WAVES
 #define SOTS_FFT_MIN_WAVES 1
 #endif
-template <int LOG2N, int MODE>
+// WIN: multiply by the fp32 window while loading (the generation loop then skips both the
+// window pass and any window work in the synthesis kernel; the product is the same single
+// fp32 rounding either way).
+template <int LOG2N, int MODE, bool WIN>
 __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
-                                               const float2 *__restrict__ tw, uint32_t p_len, float inv_n,
-                                               float inv_wf, uint32_t pitch)
+                                               const float2 *__restrict__ tw, const float *__restrict__ window,
+                                               uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave, H = E / 2;
     __shared__ float2 lds[M + M / 8 + 1];
@@ -652,6 +655,11 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
         }
     }
 
+    float2 wv[WIN ? E : 1];
+    if constexpr (WIN) {
+#pragma unroll
+        for (int s = 0; s < E; ++s) wv[s] = reinterpret_cast<const float2 *>(window)[lane + kWave * s];
+    }
     float2 x[E];
     {
         const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * pitch);
@@ -659,6 +667,10 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
         for (int s = 0; s < E; ++s) x[s] = in[lane + kWave * s];
     }
     while (true) {
+        if constexpr (WIN) {
+#pragma unroll
+            for (int s = 0; s < E; ++s) x[s] = make_float2(x[s].x * wv[s].x, x[s].y * wv[s].y);
+        }
         // the next individual's row is requested before this one is transformed, so its HBM
         // latency hides behind the passes below
         const uint32_t nxt = ind + gridDim.x;
@@ -1069,7 +1081,7 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus)
 {
     const uint32_t grid = wave_grid(p, num_cus);
-#define CALL(L) k_fft<L, 0><<<grid, kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, p, 0.f, 0.f, pitch)
+#define CALL(L) k_fft<L, 0, false><<<grid, kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
     return hipGetLastError();
@@ -1085,12 +1097,18 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
     return hipGetLastError();
 }
 
-hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *target, float *fitness,
-                              const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch, float inv_n,
-                              float inv_wf, uint32_t num_cus)
+hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *window, const float *target,
+                              float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
+                              float inv_n, float inv_wf, uint32_t num_cus)
 {
     const uint32_t grid = wave_grid(p, num_cus);
-#define CALL(L) k_fft<L, 1><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, p, inv_n, inv_wf, pitch)
+    if (window) {
+#define CALL(L) k_fft<L, 1, true><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+        SOTS_DISPATCH_LOG2N(log2n, CALL)
+#undef CALL
+        return hipGetLastError();
+    }
+#define CALL(L) k_fft<L, 1, false><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
     return hipGetLastError();
