@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=10)
     ap.add_argument("--elites", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing-every", type=int, default=8,
+                    help="record per-kernel HIP events on every k-th timed step only (0 = never)")
     args = ap.parse_args()
 
     import torch
@@ -120,11 +122,11 @@ def main():
         es.init_population(0)
         for _ in range(args.warmup):
             step()
-        es.timing_enable(True)
         es.timing_reset()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for k in range(args.steps):
+            es.timing_enable(args.timing_every > 0 and k % args.timing_every == 0)
             step()
         fence()
         dt = time.perf_counter() - t0

@@ -491,7 +491,7 @@ int sots_stage_synthesise(sots_ctx *ctx)
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_SYNTHESISE);
-        SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, nullptr,
+        SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable,
                                    ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
     }
     return maybe_drain(ctx);
@@ -586,7 +586,7 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH);
             // raw synthesis: the window is applied by the FFT kernel as it loads the row
-            SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, nullptr,
+            SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable,
                                        ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
         }
         {

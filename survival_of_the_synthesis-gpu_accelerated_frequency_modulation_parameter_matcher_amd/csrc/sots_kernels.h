@@ -50,10 +50,9 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 // ---- evaluation ----
 // Audio rows are `pitch` floats apart (pitch >= N, a multiple of 4): a power-of-two row stride
 // would put every lane of a row-per-lane store on the same memory channel.
-// window == nullptr: raw synthesis; else audio is multiplied by the fp32 window on the way out
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
-                        const float *window, float *audio, const SynthParams &sp, uint32_t p,
-                        uint32_t log2n, uint32_t pitch, uint32_t num_cus);
+                        float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
+                        uint32_t num_cus);
 hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n,
                          uint32_t pitch);
 // audio[P][pitch] -> spectrum[P][N+8]

@@ -15,6 +15,8 @@
 // Reference citations are file:line in the reference tree.
 #include "sots_kernels.h"
 
+#include <cstdlib>
+
 namespace sots {
 
 uint32_t next_pow2(uint32_t v)
@@ -177,13 +179,20 @@ __global__ __launch_bounds__(256) void k_recombine_mutate(const float *__restric
 // Objective::synthesiseAudio*, Evolutionary_Strategy.hpp:368-495.
 //
 // The oscillator phases are fp32 running sums with a conditional wrap per sample, so a
-// voice is serial in the sample index: one lane owns one individual.  The 32768-entry
-// wavetable (128 KiB) lives in LDS, one workgroup per CU; the phase chains of UNROLL
-// samples run ahead of the table reads that hang off them so that the LDS latency of a
-// gather is not on the recurrence.  Each lane stores 16 bytes at a time into its own
-// audio row.
+// voice is serial in the sample index and cannot be split over lanes without changing the
+// rounding (and with it table indices and spectra).  The 32768-entry wavetable (128 KiB)
+// lives in LDS, one workgroup per CU.  Two kernels:
+//   k_synth_pair   2-operator voice, TWO lanes per individual (modulator chain in lanes
+//                  0-31, carrier chain in lanes 32-63 of a wavefront, values handed over
+//                  with v_permlane32_swap).  At P = 65536 that puts two wavefronts on
+//                  every SIMD instead of one, so table-read latency and the row-per-lane
+//                  stores of one wavefront hide behind the other's arithmetic.
+//   k_synth        every voice, one lane per individual, phase chains of 8 samples run
+//                  ahead of the table reads that hang off them.
+// Both follow the per-sample operation order of the reference exactly.
 // ------------------------------------------------------------------------------------
-constexpr int kSynthThreads = 256;
+constexpr int kSynthThreads = 256;     // smallest workgroup: one wavefront per SIMD
+constexpr int kSynthMaxThreads = 1024; // largest: four per SIMD
 constexpr int kSynthUnroll = 8;
 constexpr float kWf = (float)kWavetableSize;
 
@@ -200,63 +209,153 @@ __device__ __forceinline__ float tab_at(const float *tab, float pos)
 __device__ __forceinline__ void wrap_hi(float &p) { if (p >= kWf) p -= kWf; }
 __device__ __forceinline__ void wrap_lo(float &p) { if (p < 0.0f) p += kWf; }
 
-// The window value of sample i is the same for every lane (lane = individual), so it does
-// not need a memory access per sample: lane l keeps window[64*chunk + l] for the current
-// 64-sample chunk in one register and sample i reads it with v_readlane(i & 63).  (Scalar
-// loads per block cost ~15 % of the kernel: with one wavefront per SIMD nothing hides them.)
-template <bool WINDOW>
-__device__ __forceinline__ void store_block(float *__restrict__ out, const float (&y)[kSynthUnroll],
-                                            float w_chunk, uint32_t i, bool active)
+__device__ __forceinline__ void load_wavetable(float *__restrict__ tab, const float *__restrict__ wavetable)
 {
-    float v[kSynthUnroll];
-#if defined(SOTS_ABLATE_WINDOW)
-#pragma unroll
-    for (int u = 0; u < kSynthUnroll; ++u) v[u] = y[u];
-#else
-#pragma unroll
-    for (int u = 0; u < kSynthUnroll; ++u) {
-        if constexpr (WINDOW) {
-            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w_chunk), (int)((i + u) & (kWave - 1))));
-            v[u] = y[u] * w;
-        } else {
-            v[u] = y[u];
-        }
-    }
-#endif
+    for (uint32_t i = threadIdx.x * 4u; i < kWavetableSize; i += blockDim.x * 4u)
+        *reinterpret_cast<float4 *>(&tab[i]) = *reinterpret_cast<const float4 *>(&wavetable[i]);
+    __syncthreads();
+}
+
+// Every wavefront of a workgroup runs the same fixed-length program, so left alone they
+// stay in lockstep: all of them read the table, then all compute, then all store, and the
+// LDS, VALU and store paths are each idle two thirds of the time.  Delaying wavefront w by
+// (w mod 4) * stagger * 64 cycles once, up front, keeps them out of phase for the whole row.
+__device__ __forceinline__ void stagger_wavefronts(uint32_t stagger)
+{
+    const uint32_t w = (threadIdx.x / kWave) & 3u;
+    for (uint32_t k = 0; k < w * stagger; ++k) __builtin_amdgcn_s_sleep(1);
+}
+
+__device__ __forceinline__ void store_block(float *__restrict__ out, const float (&y)[kSynthUnroll], uint32_t i,
+                                            bool active)
+{
 #ifdef SOTS_ABLATE_STORE
     float acc = 0.f;
 #pragma unroll
-    for (int u = 0; u < kSynthUnroll; ++u) acc += v[u];
+    for (int u = 0; u < kSynthUnroll; ++u) acc += y[u];
     if (acc == 123.456f) out[i] = acc; // timing experiment only: keeps the work alive, never stores
 #else
     if (active) {
 #pragma unroll
         for (int u = 0; u < kSynthUnroll; u += 4)
-            *reinterpret_cast<float4 *>(out + i + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+            *reinterpret_cast<float4 *>(out + i + u) = make_float4(y[u], y[u + 1], y[u + 2], y[u + 3]);
     }
 #endif
 }
 
-template <int KIND, bool WINDOW>
-__global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict__ values,
-                                                         const float *__restrict__ wavetable,
-                                                         const float *__restrict__ window,
-                                                         float *__restrict__ audio, SynthParams sp,
-                                                         uint32_t p_len, uint32_t n, uint32_t pitch)
+// ---- 2-operator voice, lane pair per individual ---------------------------------------
+constexpr int kPairThreads = 512;                        // 8 wavefronts x 32 individuals
+constexpr int kPairIndividuals = kPairThreads / 2;
+
+// One step of both chains.  Lane roles differ only in two constants:
+//   carrier  lane: step = c * (x * mod + fc)   with x = the modulator lane's table value
+//   modulator lane: step = c * (x * 0   + P0)  = c * P0, the constant modulator increment
+// (x * 0 is +-0 for the finite table values x can take, so the sum is exactly P0).
+// `slot` holds the table value this lane requested kPairLag steps ago; it is consumed and
+// then refilled with a new request, so a table read has kPairLag steps to arrive.
+constexpr int kPairLag = 4;
+constexpr int kPairTrip = 32; // steps per loop trip (N is a multiple of it)
+
+__device__ __forceinline__ float pair_step(const float *tab, float &pos, float &slot, float mul_l, float add_l, float c)
+{
+    const float told = slot;
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(told), __float_as_uint(told), false, false);
+    const float x = __uint_as_float(sw[0]); // lanes 32-63: partner lane's value; lanes 0-31: own
+    slot = tab_at(tab, pos);
+    const float cur = x * mul_l + add_l;
+    pos += c * cur;
+    wrap_hi(pos);
+    wrap_lo(pos); // never taken for the modulator chain (its phase only grows)
+    // keep this step's table request inside the step: left alone, the scheduler sinks the four
+    // requests of an unrolled iteration to its end and their latency is exposed again
+    __builtin_amdgcn_sched_barrier(0);
+    return told;
+}
+
+__global__ __launch_bounds__(kPairThreads) void k_synth_pair(const float *__restrict__ values,
+                                                             const float *__restrict__ wavetable,
+                                                             float *__restrict__ audio, SynthParams sp,
+                                                             uint32_t p_len, uint32_t n, uint32_t pitch,
+                                                             uint32_t stagger)
 {
     __shared__ float tab[kWavetableSize];
-    for (uint32_t i = threadIdx.x * 4u; i < kWavetableSize; i += kSynthThreads * 4u)
-        *reinterpret_cast<float4 *>(&tab[i]) = *reinterpret_cast<const float4 *>(&wavetable[i]);
-    __syncthreads();
+    load_wavetable(tab, wavetable);
+    stagger_wavefronts(stagger);
+    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const bool carrier = lane >= 32;
+
+    for (uint32_t base = blockIdx.x * kPairIndividuals; base < p_len; base += gridDim.x * kPairIndividuals) {
+        const uint32_t slot_id = base + wave * 32 + (lane & 31);
+        const bool active = slot_id < p_len; // all lanes keep running (the swap crosses lanes)
+        const uint32_t ind = active ? slot_id : p_len - 1u;
+        const float4 v = *reinterpret_cast<const float4 *>(values + (size_t)ind * 4);
+        // scaleParams: min + v*(max-min), ocl_program.cl:297
+        const float p0 = sp.pmin[0] + v.x * (sp.pmax[0] - sp.pmin[0]);
+        const float p1 = sp.pmin[1] + v.y * (sp.pmax[1] - sp.pmin[1]);
+        const float p2 = sp.pmin[2] + v.z * (sp.pmax[2] - sp.pmin[2]);
+        const float p3 = sp.pmin[3] + v.w * (sp.pmax[3] - sp.pmin[3]);
+        const float mod = p0 * p1, amp = p3; // Evolutionary_Strategy.hpp:372-376
+        const float mul_l = carrier ? mod : 0.0f;
+        const float add_l = carrier ? p2 : p0;
+        float *__restrict__ out = audio + (size_t)ind * pitch;
+
+        // The modulator chain runs kPairLag samples ahead of the carrier chain, and a carrier
+        // table value is turned into an output sample kPairLag steps after it was requested.
+        float pos = 0.0f;
+        float r[kPairLag];
+#pragma unroll
+        for (int u = 0; u < kPairLag; ++u) r[u] = 0.0f;
+        if (!carrier) {
+#pragma unroll
+            for (int u = 0; u < kPairLag; ++u) {
+                r[u] = tab_at(tab, pos);
+                pos += c * p0;
+                wrap_hi(pos);
+            }
+        }
+        // step j: carrier works on sample j, emits sample j - kPairLag.  Each trip of the outer
+        // loop is kPairTrip steps, fully unrolled: table requests stay in flight across the
+        // 4-step groups inside a trip and are only drained at the loop back-edge.
+        {
+            float y[kPairLag];
+#pragma unroll
+            for (int u = 0; u < kPairLag; ++u) y[u] = pair_step(tab, pos, r[u], mul_l, add_l, c) * amp; // samples < 0: dropped
+        }
+        for (uint32_t i = 0; i < n; i += kPairTrip) {
+#pragma unroll
+            for (int b = 0; b < kPairTrip; b += kPairLag) {
+                float y[kPairLag];
+#pragma unroll
+                for (int u = 0; u < kPairLag; ++u) y[u] = pair_step(tab, pos, r[u], mul_l, add_l, c) * amp;
+#ifdef SOTS_ABLATE_STORE
+                if (y[0] + y[1] + y[2] + y[3] == 123.456f) out[i] = y[0];
+#else
+                if (carrier && active) *reinterpret_cast<float4 *>(out + i + b) = make_float4(y[0], y[1], y[2], y[3]);
+#endif
+            }
+        }
+    }
+}
+
+// ---- every voice, one lane per individual ------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(kSynthMaxThreads) void k_synth(const float *__restrict__ values,
+                                                         const float *__restrict__ wavetable,
+                                                         float *__restrict__ audio, SynthParams sp,
+                                                         uint32_t p_len, uint32_t n, uint32_t pitch,
+                                                         uint32_t stagger)
+{
+    __shared__ float tab[kWavetableSize];
+    load_wavetable(tab, wavetable);
+    stagger_wavefronts(stagger);
 
     constexpr int D = KIND == SOTS_SYNTH_2OP ? 4 : KIND == SOTS_SYNTH_3OP_SERIES ? 6
                     : KIND == SOTS_SYNTH_TRIPLE_PAR ? 12 : 8;
     // w2srRatio, Evolutionary_Strategy.hpp:203
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
 
-    for (uint32_t base = blockIdx.x * kSynthThreads; base < p_len; base += gridDim.x * kSynthThreads) {
-        // Every lane stays active (the window register is read across lanes): lanes past the
-        // end redo the last individual and never store.
+    for (uint32_t base = blockIdx.x * blockDim.x; base < p_len; base += gridDim.x * blockDim.x) {
         const bool active = base + threadIdx.x < p_len;
         const uint32_t ind = active ? base + threadIdx.x : p_len - 1u;
         float p[D];
@@ -269,20 +368,17 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
         }
         float *__restrict__ out = audio + (size_t)ind * pitch;
 
-        const int lane = threadIdx.x & (kWave - 1);
         if constexpr (KIND == SOTS_SYNTH_2OP) {
             // Evolutionary_Strategy.hpp:372-401, as a three-stage software pipeline over blocks of
             // 8 samples so that no table read is waited for in the phase that issues it:
             //   stage A (block b+1): modulator phase chain, issues its 8 table reads
             //   stage B (block b)  : carrier phase chain from A's values, issues the 8 output reads
-            //   stage C (block b-1): amplitude, window, 16-byte stores
+            //   stage C (block b-1): amplitude, 16-byte stores
             // Same arithmetic in the same per-sample order as the serial loop.
             const float mod = p[0] * p[1], fc = p[2], amp = p[3];
             const float inc1 = c * p[0];
             float pos1 = 0.0f, pos2 = 0.0f;
             float t1[kSynthUnroll], t1n[kSynthUnroll], y[kSynthUnroll], yp[kSynthUnroll];
-            float w_cur = 0.0f, w_next = 0.0f;
-            if constexpr (WINDOW) w_next = window[lane];
 #pragma unroll
             for (int u = 0; u < kSynthUnroll; ++u) {
                 t1[u] = tab_at(tab, pos1);
@@ -307,16 +403,9 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                     wrap_lo(pos2);
                 }
                 if (i > 0) {
-                    const uint32_t ip = i - kSynthUnroll;
-                    if constexpr (WINDOW) {
-                        if ((ip & (kWave - 1)) == 0) { // entering a new 64-sample chunk
-                            w_cur = w_next;
-                            if (ip + kWave < n) w_next = window[ip + kWave + lane];
-                        }
-                    }
 #pragma unroll
                     for (int u = 0; u < kSynthUnroll; ++u) yp[u] = yp[u] * amp;
-                    store_block<WINDOW>(out, yp, w_cur, ip, active);
+                    store_block(out, yp, i - kSynthUnroll, active);
                 }
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u) {
@@ -324,15 +413,9 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                     yp[u] = y[u];
                 }
             }
-            {
-                const uint32_t ip = n - kSynthUnroll;
-                if constexpr (WINDOW) {
-                    if ((ip & (kWave - 1)) == 0) w_cur = w_next;
-                }
 #pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u) yp[u] = yp[u] * amp;
-                store_block<WINDOW>(out, yp, w_cur, ip, active);
-            }
+            for (int u = 0; u < kSynthUnroll; ++u) yp[u] = yp[u] * amp;
+            store_block(out, yp, n - kSynthUnroll, active);
         } else if constexpr (KIND == SOTS_SYNTH_3OP_SERIES || KIND == SOTS_SYNTH_4OP_SERIES) {
             // Evolutionary_Strategy.hpp:407-445; the 4-op voice adds one more modulator stage
             constexpr int OPS = KIND == SOTS_SYNTH_3OP_SERIES ? 3 : 4;
@@ -343,11 +426,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
             float pos[OPS];
 #pragma unroll
             for (int o = 0; o < OPS; ++o) pos[o] = 0.0f;
-            float w_cur = 0.0f;
             for (uint32_t i = 0; i < n; i += kSynthUnroll) {
-                if constexpr (WINDOW) {
-                    if ((i & (kWave - 1)) == 0) w_cur = window[i + lane];
-                }
                 float t[kSynthUnroll], y[kSynthUnroll];
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u) {
@@ -370,7 +449,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                 }
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u) y[u] = t[u] * m[OPS - 1];
-                store_block<WINDOW>(out, y, w_cur, i, active);
+                store_block(out, y, i, active);
             }
         } else {
             // Evolutionary_Strategy.hpp:457-494
@@ -384,11 +463,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
                 pa[j] = 0.0f;
                 pb[j] = 0.0f;
             }
-            float w_cur = 0.0f;
             for (uint32_t i = 0; i < n; i += kSynthUnroll) {
-                if constexpr (WINDOW) {
-                    if ((i & (kWave - 1)) == 0) w_cur = window[i + lane];
-                }
                 float tot[3][kSynthUnroll], y[kSynthUnroll];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -411,7 +486,7 @@ __global__ __launch_bounds__(kSynthThreads) void k_synth(const float *__restrict
 #pragma unroll
                 for (int u = 0; u < kSynthUnroll; ++u)
                     y[u] = (tot[0][u] + tot[1][u] + tot[2][u]) / 3.0f; // == (float)(double(sum)/3.0), :493
-                store_block<WINDOW>(out, y, w_cur, i, active);
+                store_block(out, y, i, active);
             }
         }
     }
@@ -542,11 +617,63 @@ __device__ __forceinline__ void lds_reload(float2 (&x)[M / kWave], const float2 
     for (int s = 0; s < M / kWave; ++s) x[s] = lds[lds_pad(lane + kWave * s)];
 }
 
-// All passes for M complex points; leaves Z in natural order in LDS (padded indexing).
+// First pass (NS = 1, no twiddles) straight from the 16-byte loads of the row.  Lane l holds
+// the float4 = two complex points at pair index l + 64 h, i.e. complex elements
+// e0 = 2l + 128 h and e0 + 1.  With element e = j + (M/R) t:
+//   B = E/R >= 2: the lane already owns every t of butterflies j = 2l + 64 bb (+1), bb even;
+//   B == 1      : lanes l and l+32 hold the even-t and odd-t halves of butterflies 2l, 2l+1;
+//                 one v_permlane32_swap per register gives lane l all of 2l and lane l+32
+//                 all of 2l+1.
+template <int M, int R>
+__device__ __forceinline__ void fft_first_pass(const float4 (&q)[M / kWave / 2], float2 *__restrict__ lds, int lane)
+{
+    constexpr int E = M / kWave, B = E / R;
+    static_assert(E % R == 0 && (B == 1 || B % 2 == 0), "unsupported first-pass shape");
+    if constexpr (B == 1) {
+        float2 v[R];
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[h].x), __float_as_uint(q[h].z), false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[h].y), __float_as_uint(q[h].w), false, false);
+            v[2 * h] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+            v[2 * h + 1] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
+        }
+        Dft<R>::run(v);
+        const int j = 2 * (lane & 31) + (lane >> 5);
+#pragma unroll
+        for (int t = 0; t < R; ++t) lds[lds_pad(j * R + t)] = v[t];
+    } else {
+#pragma unroll
+        for (int bb = 0; bb < B; bb += 2) {
+            float2 v0[R], v1[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const int h = (t * B + bb) / 2;
+                v0[t] = make_float2(q[h].x, q[h].y);
+                v1[t] = make_float2(q[h].z, q[h].w);
+            }
+            Dft<R>::run(v0);
+            Dft<R>::run(v1);
+            const int j = 2 * lane + kWave * bb;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                lds[lds_pad(j * R + t)] = v0[t];
+                lds[lds_pad((j + 1) * R + t)] = v1[t];
+            }
+        }
+    }
+}
+
+// All passes for M complex points, starting from the row as loaded; leaves Z in natural
+// order in LDS (padded indexing).
 template <int M>
-__device__ __forceinline__ void fft_forward(float2 (&x)[M / kWave], float2 *__restrict__ lds,
+__device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], float2 *__restrict__ lds,
                                             const float2 *__restrict__ tw, int lane)
 {
+    float2 x[M / kWave];
+#define SOTS_FIRST(R)                        \
+    fft_first_pass<M, R>(q, lds, lane);      \
+    __syncthreads();
 #define SOTS_PASS(R, NS)                     \
     fft_pass<M, R, NS>(x, lds, tw, lane);    \
     __syncthreads();
@@ -554,17 +681,18 @@ __device__ __forceinline__ void fft_forward(float2 (&x)[M / kWave], float2 *__re
     lds_reload<M>(x, lds, lane);             \
     __syncthreads();
     if constexpr (M == 256) {
-        SOTS_PASS(4, 1) SOTS_NEXT() SOTS_PASS(4, 4) SOTS_NEXT() SOTS_PASS(4, 16) SOTS_NEXT() SOTS_PASS(4, 64)
+        SOTS_FIRST(4) SOTS_NEXT() SOTS_PASS(4, 4) SOTS_NEXT() SOTS_PASS(4, 16) SOTS_NEXT() SOTS_PASS(4, 64)
     } else if constexpr (M == 512) {
-        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64)
     } else if constexpr (M == 1024) {
-        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(4, 64) SOTS_NEXT() SOTS_PASS(4, 256)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(4, 64) SOTS_NEXT() SOTS_PASS(4, 256)
     } else if constexpr (M == 2048) {
-        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(4, 512)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(4, 512)
     } else {
         static_assert(M == 4096, "unsupported FFT length");
-        SOTS_PASS(8, 1) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(8, 512)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(8, 512)
     }
+#undef SOTS_FIRST
 #undef SOTS_PASS
 #undef SOTS_NEXT
 }
@@ -655,31 +783,34 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
         }
     }
 
-    float2 wv[WIN ? E : 1];
+    // rows are read 16 bytes per lane: pair index lane + 64 h holds complex points 2(lane+64h), +1
+    constexpr int Q = E / 2;
+    float4 wv[WIN ? Q : 1];
     if constexpr (WIN) {
 #pragma unroll
-        for (int s = 0; s < E; ++s) wv[s] = reinterpret_cast<const float2 *>(window)[lane + kWave * s];
+        for (int h = 0; h < Q; ++h) wv[h] = reinterpret_cast<const float4 *>(window)[lane + kWave * h];
     }
-    float2 x[E];
+    float4 x[Q];
     {
-        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * pitch);
+        const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)ind * pitch);
 #pragma unroll
-        for (int s = 0; s < E; ++s) x[s] = in[lane + kWave * s];
+        for (int h = 0; h < Q; ++h) x[h] = in[lane + kWave * h];
     }
     while (true) {
         if constexpr (WIN) {
 #pragma unroll
-            for (int s = 0; s < E; ++s) x[s] = make_float2(x[s].x * wv[s].x, x[s].y * wv[s].y);
+            for (int h = 0; h < Q; ++h)
+                x[h] = make_float4(x[h].x * wv[h].x, x[h].y * wv[h].y, x[h].z * wv[h].z, x[h].w * wv[h].w);
         }
         // the next individual's row is requested before this one is transformed, so its HBM
         // latency hides behind the passes below
         const uint32_t nxt = ind + gridDim.x;
         const bool more = nxt < p_len;
-        float2 y[E];
+        float4 y[Q];
         {
-            const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : ind) * pitch);
+            const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(more ? nxt : ind) * pitch);
 #pragma unroll
-            for (int s = 0; s < E; ++s) y[s] = in[lane + kWave * s];
+            for (int h = 0; h < Q; ++h) y[h] = in[lane + kWave * h];
         }
         fft_forward<M>(x, lds, tw, lane);
         const float2 zh = lds[lds_pad(M / 2)];
@@ -712,7 +843,7 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
         if (!more) break;
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < E; ++s) x[s] = y[s];
+        for (int h = 0; h < Q; ++h) x[h] = y[h];
         ind = nxt;
     }
 }
@@ -1024,32 +1155,43 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
     return hipGetLastError();
 }
 
-template <int KIND>
-static hipError_t launch_synth_kind(hipStream_t st, const float *values, const float *wavetable,
-                                    const float *window, float *audio, const SynthParams &sp, uint32_t p,
-                                    uint32_t n, uint32_t pitch, uint32_t grid)
-{
-    if (window)
-        k_synth<KIND, true><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n, pitch);
-    else
-        k_synth<KIND, false><<<grid, kSynthThreads, 0, st>>>(values, wavetable, window, audio, sp, p, n, pitch);
-    return hipGetLastError();
-}
+#ifndef SOTS_SYNTH_PAIR
+#define SOTS_SYNTH_PAIR 1
+#endif
 
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
-                        const float *window, float *audio, const SynthParams &sp, uint32_t p,
-                        uint32_t log2n, uint32_t pitch, uint32_t num_cus)
+                        float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
+                        uint32_t num_cus)
 {
     const uint32_t n = 1u << log2n;
-    // one 128 KiB-LDS workgroup per CU; further individuals are taken in a block-stride loop
-    const uint32_t grid = grid_for(p, kSynthThreads, num_cus ? num_cus : 256);
+    const uint32_t cus = num_cus ? num_cus : 256;
+    // The 128 KiB table allows one workgroup per CU, so the workgroup is sized to the CU's share
+    // of the population: more wavefronts per SIMD hide more of the table-read and store latency.
+    const uint32_t share = (p + cus - 1) / cus;
+    static const uint32_t stagger = [] {
+        const char *e = getenv("SOTS_SYNTH_STAGGER"); // development knob, units of 64 cycles
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
+    }();
+    static const bool use_pair = [] {
+        const char *e = getenv("SOTS_SYNTH_PAIR");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (kind == SOTS_SYNTH_2OP && SOTS_SYNTH_PAIR && use_pair && share <= (uint32_t)kPairIndividuals) {
+        // small share: two lanes per individual double the wavefronts per SIMD
+        k_synth_pair<<<grid_for(p, kPairIndividuals, cus), kPairThreads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger);
+        return hipGetLastError();
+    }
+    uint32_t threads = ((share + kWave - 1) / kWave) * kWave;
+    threads = threads < (uint32_t)kSynthThreads ? (uint32_t)kSynthThreads : threads > (uint32_t)kSynthMaxThreads ? (uint32_t)kSynthMaxThreads : threads;
+    const uint32_t grid = grid_for(p, threads, cus);
     switch (kind) {
-    case SOTS_SYNTH_2OP: return launch_synth_kind<SOTS_SYNTH_2OP>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
-    case SOTS_SYNTH_3OP_SERIES: return launch_synth_kind<SOTS_SYNTH_3OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
-    case SOTS_SYNTH_TRIPLE_PAR: return launch_synth_kind<SOTS_SYNTH_TRIPLE_PAR>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
-    case SOTS_SYNTH_4OP_SERIES: return launch_synth_kind<SOTS_SYNTH_4OP_SERIES>(st, values, wavetable, window, audio, sp, p, n, pitch, grid);
+    case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
+    case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
+    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
+    case SOTS_SYNTH_4OP_SERIES: k_synth<SOTS_SYNTH_4OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
 }
 
 hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n,
