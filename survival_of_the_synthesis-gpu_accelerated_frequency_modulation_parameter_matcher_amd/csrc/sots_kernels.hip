@@ -583,10 +583,24 @@ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 3); }
 // One Stockham pass of radix R with NS = product of the radices already applied.
 // Register slot s holds element lane + 64 s of the pass input; butterfly b uses slots
 // b + t*(E/R), t < R.  Output element t of butterfly j goes to (j-k)*R + k + t*NS with
-// k = j mod NS.
+// k = j mod NS.  The twiddles e^{-2 pi i t k / (NS R)} depend only on the lane, so they are
+// loop-invariant per kernel: twr (when non-null) holds them in registers, B*(R-1) values in
+// (b, t) order; otherwise they come from the N-entry table e^{-2 pi i q / N}, N = 2M.
+template <int M, int R, int NS>
+__device__ __forceinline__ void load_pass_twiddles(float2 *twr, const float2 *__restrict__ tw, int lane)
+{
+    constexpr int E = M / kWave, B = E / R, stride = (2 * M) / (NS * R);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int k = (lane + kWave * b) & (NS - 1);
+#pragma unroll
+        for (int t = 1; t < R; ++t) twr[b * (R - 1) + t - 1] = tw[t * k * stride];
+    }
+}
+
 template <int M, int R, int NS>
 __device__ __forceinline__ void fft_pass(float2 (&x)[M / kWave], float2 *__restrict__ lds,
-                                         const float2 *__restrict__ tw, int lane)
+                                         const float2 *__restrict__ tw, const float2 *twr, int lane)
 {
     constexpr int E = M / kWave, B = E / R;
     static_assert(E % R == 0, "radix must divide the per-lane element count");
@@ -598,10 +612,9 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[M / kWave], float2 *__restr
 #pragma unroll
         for (int t = 0; t < R; ++t) v[t] = x[b + t * B];
         if constexpr (NS > 1) {
-            // twiddle e^{-2 pi i t k / (NS R)} from the N-entry table e^{-2 pi i q / N}, N = 2M
             constexpr int stride = (2 * M) / (NS * R);
 #pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], tw[t * k * stride]);
+            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], twr ? twr[b * (R - 1) + t - 1] : tw[t * k * stride]);
         }
         Dft<R>::run(v);
         const int j0 = (j - k) * R + k;
@@ -666,32 +679,58 @@ __device__ __forceinline__ void fft_first_pass(const float4 (&q)[M / kWave / 2],
 
 // All passes for M complex points, starting from the row as loaded; leaves Z in natural
 // order in LDS (padded indexing).
+// Number of per-lane pass twiddles (all passes after the first) and whether the kernels keep
+// them in registers: yes up to M = 1024; beyond that they would not fit next to the data.
+template <int M> constexpr int tw_count() { return M == 256 ? 9 : M == 512 ? 14 : M == 1024 ? 38 : 1; }
+template <int M> constexpr bool tw_in_regs() { return M <= 1024; }
+
+template <int M>
+__device__ __forceinline__ void preload_twiddles(float2 (&twr)[tw_count<M>()], const float2 *__restrict__ tw, int lane)
+{
+    if constexpr (M == 256) {
+        load_pass_twiddles<M, 4, 4>(&twr[0], tw, lane);
+        load_pass_twiddles<M, 4, 16>(&twr[3], tw, lane);
+        load_pass_twiddles<M, 4, 64>(&twr[6], tw, lane);
+    } else if constexpr (M == 512) {
+        load_pass_twiddles<M, 8, 8>(&twr[0], tw, lane);
+        load_pass_twiddles<M, 8, 64>(&twr[7], tw, lane);
+    } else if constexpr (M == 1024) {
+        load_pass_twiddles<M, 8, 8>(&twr[0], tw, lane);
+        load_pass_twiddles<M, 4, 64>(&twr[14], tw, lane);
+        load_pass_twiddles<M, 4, 256>(&twr[26], tw, lane);
+    } else {
+        twr[0] = make_float2(0.f, 0.f);
+    }
+}
+
 template <int M>
 __device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], float2 *__restrict__ lds,
-                                            const float2 *__restrict__ tw, int lane)
+                                            const float2 *__restrict__ tw, const float2 (&twr)[tw_count<M>()], int lane)
 {
     float2 x[M / kWave];
+#define SOTS_SYNC() __syncthreads()
 #define SOTS_FIRST(R)                        \
     fft_first_pass<M, R>(q, lds, lane);      \
-    __syncthreads();
-#define SOTS_PASS(R, NS)                     \
-    fft_pass<M, R, NS>(x, lds, tw, lane);    \
-    __syncthreads();
+    SOTS_SYNC();
+#define SOTS_PASS(R, NS, OFF)                                                        \
+    fft_pass<M, R, NS>(x, lds, tw, tw_in_regs<M>() ? &twr[OFF] : nullptr, lane);     \
+    SOTS_SYNC();
 #define SOTS_NEXT()                          \
     lds_reload<M>(x, lds, lane);             \
-    __syncthreads();
+    SOTS_SYNC();
     if constexpr (M == 256) {
-        SOTS_FIRST(4) SOTS_NEXT() SOTS_PASS(4, 4) SOTS_NEXT() SOTS_PASS(4, 16) SOTS_NEXT() SOTS_PASS(4, 64)
+        SOTS_FIRST(4) SOTS_NEXT() SOTS_PASS(4, 4, 0) SOTS_NEXT() SOTS_PASS(4, 16, 3) SOTS_NEXT() SOTS_PASS(4, 64, 6)
     } else if constexpr (M == 512) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 7)
     } else if constexpr (M == 1024) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(4, 64) SOTS_NEXT() SOTS_PASS(4, 256)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(4, 64, 14) SOTS_NEXT() SOTS_PASS(4, 256, 26)
     } else if constexpr (M == 2048) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(4, 512)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_PASS(4, 512, 0)
     } else {
         static_assert(M == 4096, "unsupported FFT length");
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8) SOTS_NEXT() SOTS_PASS(8, 64) SOTS_NEXT() SOTS_PASS(8, 512)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_PASS(8, 512, 0)
     }
+#undef SOTS_SYNC
 #undef SOTS_FIRST
 #undef SOTS_PASS
 #undef SOTS_NEXT
@@ -790,6 +829,8 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
 #pragma unroll
         for (int h = 0; h < Q; ++h) wv[h] = reinterpret_cast<const float4 *>(window)[lane + kWave * h];
     }
+    float2 twr[tw_count<M>()];
+    preload_twiddles<M>(twr, tw, lane);
     float4 x[Q];
     {
         const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)ind * pitch);
@@ -812,7 +853,7 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
 #pragma unroll
             for (int h = 0; h < Q; ++h) y[h] = in[lane + kWave * h];
         }
-        fft_forward<M>(x, lds, tw, lane);
+        fft_forward<M>(x, lds, tw, twr, lane);
         const float2 zh = lds[lds_pad(M / 2)];
         const float2 x_half = make_float2(zh.x, -zh.y); // bin M/2
         if constexpr (MODE == 0) {
@@ -1212,18 +1253,27 @@ hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint
     default: return hipErrorInvalidValue; \
     }
 
-static uint32_t wave_grid(uint32_t p, uint32_t num_cus)
+// Grid of a grid-stride kernel whose items all cost the same: exactly as many workgroups as
+// are resident at once (occupancy query, cached per kernel).  A larger grid runs in rounds
+// and the last, partly filled round costs as much as a full one (measured: 4096 one-wave
+// workgroups on 3072 slots took 1.5x the time of 3072).
+template <typename K>
+static uint32_t resident_grid(K kernel, int threads, uint32_t items, uint32_t num_cus, int *cache)
 {
-    // one wavefront per individual; enough workgroups to fill every CU several times over
-    const uint32_t cap = (num_cus ? num_cus : 256) * 16;
-    return p < cap ? p : cap;
+    if (*cache == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        *cache = per_cu;
+    }
+    const uint64_t cap = (uint64_t)(num_cus ? num_cus : 256) * (uint64_t)*cache;
+    return (uint32_t)(items < cap ? items : cap);
 }
 
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus)
 {
-    const uint32_t grid = wave_grid(p, num_cus);
-#define CALL(L) k_fft<L, 0, false><<<grid, kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
+    static int occ[16] = {0};
+#define CALL(L) k_fft<L, 0, false><<<resident_grid(k_fft<L, 0, false>, kWave, p, num_cus, &occ[L]), kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
     return hipGetLastError();
@@ -1232,8 +1282,8 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus)
 {
-    const uint32_t grid = wave_grid(p, num_cus);
-#define CALL(L) k_fitness<L><<<grid, kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
+    static int occ[16] = {0};
+#define CALL(L) k_fitness<L><<<resident_grid(k_fitness<L>, kWave, p, num_cus, &occ[L]), kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
     return hipGetLastError();
@@ -1243,14 +1293,14 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
                               float inv_n, float inv_wf, uint32_t num_cus)
 {
-    const uint32_t grid = wave_grid(p, num_cus);
+    static int occ_w[16] = {0}, occ_n[16] = {0};
     if (window) {
-#define CALL(L) k_fft<L, 1, true><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+#define CALL(L) k_fft<L, 1, true><<<resident_grid(k_fft<L, 1, true>, kWave, p, num_cus, &occ_w[L]), kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
         SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
         return hipGetLastError();
     }
-#define CALL(L) k_fft<L, 1, false><<<grid, kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
+#define CALL(L) k_fft<L, 1, false><<<resident_grid(k_fft<L, 1, false>, kWave, p, num_cus, &occ_n[L]), kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
     return hipGetLastError();

@@ -250,6 +250,23 @@ def test_fused_generation_equals_staged(pkg, O, kind, log2n, parents, offspring)
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (0, 9, 30, 35), (3, 12, 32, 96)])
+def test_audio_after_fused_loop_is_the_raw_synthesis(pkg, O, kind, log2n, parents, offspring):
+    """The fused loop keeps the audio in its own (tiled) layout and leaves the window to the FFT
+    kernel: sots_read_synth must still return dense, un-windowed rows."""
+    block = 1 if (parents + offspring) % 32 else 32
+    a, _ = make_pair(pkg, O, parents, offspring, kind, log2n, block=block)
+    b, _ = make_pair(pkg, O, parents, offspring, kind, log2n, block=block)
+    tgt, _ = target_audio(O, kind, a.N)
+    for es in (a, b):
+        es.set_target_audio(tgt)
+        es.init_population(0)
+    a.execute_generations(1)
+    b.recombine(); b.mutate(); b.synthesise()
+    assert np.array_equal(a.read_audio(), b.read_audio())
+    a.close(); b.close()
+
+
 def test_config2_trajectory_per_generation_parity(pkg, O):
     """BASELINE config 2: P=1024 (256+768), 2-op, N=1024.  Each generation the oracle is
     re-synchronised to the device's pre-generation state, runs the same generation, and both
