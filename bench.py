@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--log2n", type=int, default=10)
     ap.add_argument("--elites", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --share-gpu rehearses N > 1 on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="map every rank to cuda:0 (rehearsal only)")
     ap.add_argument("--timing-every", type=int, default=8,
                     help="record per-kernel HIP events on every k-th timed step only (0 = never)")
     args = ap.parse_args()
@@ -90,11 +93,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = importlib.import_module(PKG)
     P = args.parents + args.offspring

@@ -165,6 +165,10 @@ int sots_stage_time_ms(sots_ctx *ctx, int stage, double *total_ms, uint64_t *cou
  * device and run on its stream (no host sync); *_host are blocking. */
 int sots_pack_elites_device(sots_ctx *ctx, void *device_rows, uint32_t n_rows);
 int sots_inject_immigrants_device(sots_ctx *ctx, const void *device_rows, uint32_t n_rows);
+/* gathered_rows = the all-gather result, world x elites rows in rank order: injects every
+ * island's rows except this rank's own block (one launch, no intermediate copy) */
+int sots_inject_gathered_device(sots_ctx *ctx, const void *gathered_rows, uint32_t world, uint32_t rank,
+                                uint32_t elites);
 int sots_pack_elites_host(sots_ctx *ctx, float *rows, uint32_t n_rows);
 int sots_inject_immigrants_host(sots_ctx *ctx, const float *rows, uint32_t n_rows);
 

@@ -41,7 +41,7 @@ EXPORTS = [
     "sots_stage_fft", "sots_stage_fitness", "sots_stage_sort", "sots_stage_rotate",
     "sots_execute_generation", "sots_execute_generations", "sots_get_generation",
     "sots_set_generation", "sots_timing_enable", "sots_timing_reset", "sots_stage_time_ms",
-    "sots_pack_elites_device", "sots_inject_immigrants_device", "sots_pack_elites_host",
+    "sots_pack_elites_device", "sots_inject_immigrants_device", "sots_inject_gathered_device", "sots_pack_elites_host",
     "sots_inject_immigrants_host", "sots_get_info",
 ]
 
@@ -112,6 +112,7 @@ def load():
     L.sots_stage_time_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sots_pack_elites_device.argtypes = [vp, vp, u32]
     L.sots_inject_immigrants_device.argtypes = [vp, vp, u32]
+    L.sots_inject_gathered_device.argtypes = [vp, vp, u32, u32, u32]
     L.sots_pack_elites_host.argtypes = [vp, vp, u32]
     L.sots_inject_immigrants_host.argtypes = [vp, vp, u32]
     L.sots_get_info.argtypes = [vp, C.POINTER(Info)]
@@ -303,6 +304,9 @@ class HipES:
 
     def inject_immigrants_device(self, dev_ptr, n_rows):
         self._check(self.L.sots_inject_immigrants_device(self._h, C.c_void_p(dev_ptr), n_rows))
+
+    def inject_gathered_device(self, dev_ptr, world, rank, elites):
+        self._check(self.L.sots_inject_gathered_device(self._h, C.c_void_p(dev_ptr), world, rank, elites))
 
     def pack_elites(self, n_rows):
         rows = np.empty((n_rows, 2 * self.D + 1), np.float32)

@@ -672,7 +672,23 @@ int sots_inject_immigrants_device(sots_ctx *ctx, const void *device_rows, uint32
         return fail(ctx, SOTS_ERR_INVALID, "inject_immigrants: %u rows do not fit %u parents", n_rows, ctx->cfg.num_parents);
     if (int rc = bind_device(ctx)) return rc;
     SOTS_HIP(ctx, launch_unpack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
-                                     (const float *)device_rows, ctx->cfg.num_parents - n_rows, n_rows, ctx->D));
+                                     (const float *)device_rows, ctx->cfg.num_parents - n_rows, n_rows, ctx->D, 0, 0));
+    return SOTS_OK;
+}
+
+int sots_inject_gathered_device(sots_ctx *ctx, const void *gathered_rows, uint32_t world, uint32_t rank, uint32_t elites)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (!gathered_rows || world == 0 || rank >= world)
+        return fail(ctx, SOTS_ERR_INVALID, "inject_gathered: bad arguments (world %u, rank %u)", world, rank);
+    const uint64_t n_rows = (uint64_t)(world - 1) * elites;
+    if (n_rows > ctx->cfg.num_parents)
+        return fail(ctx, SOTS_ERR_INVALID, "inject_gathered: %llu immigrant rows do not fit %u parents",
+                    (unsigned long long)n_rows, ctx->cfg.num_parents);
+    if (int rc = bind_device(ctx)) return rc;
+    SOTS_HIP(ctx, launch_unpack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
+                                     (const float *)gathered_rows, ctx->cfg.num_parents - (uint32_t)n_rows, (uint32_t)n_rows,
+                                     ctx->D, rank * elites, elites));
     return SOTS_OK;
 }
 

@@ -76,8 +76,10 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
 // ---- island exchange ----
 hipError_t launch_pack_rows(hipStream_t st, const float *values, const float *steps, const float *fitness,
                             float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d);
+// source rows [skip_first, skip_first + skip_count) are passed over
 hipError_t launch_unpack_rows(hipStream_t st, float *values, float *steps, float *fitness,
-                              const float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d);
+                              const float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d,
+                              uint32_t skip_first, uint32_t skip_count);
 
 uint32_t next_pow2(uint32_t v);
 

@@ -216,16 +216,6 @@ __device__ __forceinline__ void load_wavetable(float *__restrict__ tab, const fl
     __syncthreads();
 }
 
-// Every wavefront of a workgroup runs the same fixed-length program, so left alone they
-// stay in lockstep: all of them read the table, then all compute, then all store, and the
-// LDS, VALU and store paths are each idle two thirds of the time.  Delaying wavefront w by
-// (w mod 4) * stagger * 64 cycles once, up front, keeps them out of phase for the whole row.
-__device__ __forceinline__ void stagger_wavefronts(uint32_t stagger)
-{
-    const uint32_t w = (threadIdx.x / kWave) & 3u;
-    for (uint32_t k = 0; k < w * stagger; ++k) __builtin_amdgcn_s_sleep(1);
-}
-
 __device__ __forceinline__ void store_block(float *__restrict__ out, const float (&y)[kSynthUnroll], uint32_t i,
                                             bool active)
 {
@@ -275,12 +265,10 @@ __device__ __forceinline__ float pair_step(const float *tab, float &pos, float &
 __global__ __launch_bounds__(kPairThreads) void k_synth_pair(const float *__restrict__ values,
                                                              const float *__restrict__ wavetable,
                                                              float *__restrict__ audio, SynthParams sp,
-                                                             uint32_t p_len, uint32_t n, uint32_t pitch,
-                                                             uint32_t stagger)
+                                                             uint32_t p_len, uint32_t n, uint32_t pitch)
 {
     __shared__ float tab[kWavetableSize];
     load_wavetable(tab, wavetable);
-    stagger_wavefronts(stagger);
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const bool carrier = lane >= 32;
@@ -343,12 +331,10 @@ template <int KIND>
 __global__ __launch_bounds__(kSynthMaxThreads) void k_synth(const float *__restrict__ values,
                                                          const float *__restrict__ wavetable,
                                                          float *__restrict__ audio, SynthParams sp,
-                                                         uint32_t p_len, uint32_t n, uint32_t pitch,
-                                                         uint32_t stagger)
+                                                         uint32_t p_len, uint32_t n, uint32_t pitch)
 {
     __shared__ float tab[kWavetableSize];
     load_wavetable(tab, wavetable);
-    stagger_wavefronts(stagger);
 
     constexpr int D = KIND == SOTS_SYNTH_2OP ? 4 : KIND == SOTS_SYNTH_3OP_SERIES ? 6
                     : KIND == SOTS_SYNTH_TRIPLE_PAR ? 12 : 8;
@@ -1139,14 +1125,18 @@ __global__ void k_pack_rows(const float *__restrict__ values, const float *__res
     }
 }
 
+// rows [skip_first, skip_first + skip_count) of the source are passed over (an island's own
+// block inside an all-gathered buffer)
 __global__ void k_unpack_rows(float *__restrict__ values, float *__restrict__ steps,
                               float *__restrict__ fitness, const float *__restrict__ rows,
-                              uint32_t first_row, uint32_t n_rows, uint32_t d)
+                              uint32_t first_row, uint32_t n_rows, uint32_t d, uint32_t skip_first,
+                              uint32_t skip_count)
 {
     const uint32_t w = 2 * d + 1, total = n_rows * w;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const uint32_t r = e / w, c = e - r * w, dst = first_row + r;
-        const float v = rows[e];
+        const uint32_t sr = r < skip_first ? r : r + skip_count;
+        const float v = rows[sr * w + c];
         if (c == 0) fitness[dst] = v;
         else if (c <= d) values[dst * d + (c - 1)] = v;
         else steps[dst * d + (c - 1 - d)] = v;
@@ -1209,27 +1199,23 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     // The 128 KiB table allows one workgroup per CU, so the workgroup is sized to the CU's share
     // of the population: more wavefronts per SIMD hide more of the table-read and store latency.
     const uint32_t share = (p + cus - 1) / cus;
-    static const uint32_t stagger = [] {
-        const char *e = getenv("SOTS_SYNTH_STAGGER"); // development knob, units of 64 cycles
-        return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
-    }();
     static const bool use_pair = [] {
         const char *e = getenv("SOTS_SYNTH_PAIR");
         return e ? atoi(e) != 0 : true;
     }();
     if (kind == SOTS_SYNTH_2OP && SOTS_SYNTH_PAIR && use_pair && share <= (uint32_t)kPairIndividuals) {
         // small share: two lanes per individual double the wavefronts per SIMD
-        k_synth_pair<<<grid_for(p, kPairIndividuals, cus), kPairThreads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger);
+        k_synth_pair<<<grid_for(p, kPairIndividuals, cus), kPairThreads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
         return hipGetLastError();
     }
     uint32_t threads = ((share + kWave - 1) / kWave) * kWave;
     threads = threads < (uint32_t)kSynthThreads ? (uint32_t)kSynthThreads : threads > (uint32_t)kSynthMaxThreads ? (uint32_t)kSynthMaxThreads : threads;
     const uint32_t grid = grid_for(p, threads, cus);
     switch (kind) {
-    case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
-    case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
-    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
-    case SOTS_SYNTH_4OP_SERIES: k_synth<SOTS_SYNTH_4OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, stagger); break;
+    case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+    case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+    case SOTS_SYNTH_4OP_SERIES: k_synth<SOTS_SYNTH_4OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1379,11 +1365,13 @@ hipError_t launch_pack_rows(hipStream_t st, const float *values, const float *st
 }
 
 hipError_t launch_unpack_rows(hipStream_t st, float *values, float *steps, float *fitness,
-                              const float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d)
+                              const float *rows, uint32_t first_row, uint32_t n_rows, uint32_t d,
+                              uint32_t skip_first, uint32_t skip_count)
 {
     if (n_rows == 0) return hipSuccess;
     k_unpack_rows<<<grid_for((uint64_t)n_rows * (2 * d + 1), 256), 256, 0, st>>>(values, steps, fitness, rows,
-                                                                                 first_row, n_rows, d);
+                                                                                 first_row, n_rows, d, skip_first,
+                                                                                 skip_count);
     return hipGetLastError();
 }
 

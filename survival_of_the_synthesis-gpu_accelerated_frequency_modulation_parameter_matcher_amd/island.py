@@ -26,15 +26,19 @@ class IslandExchange:
     def num_immigrants(self) -> int:
         return (self.world - 1) * self.E
 
-    def gather(self) -> torch.Tensor:
-        """all-gather self.mine; returns the other islands' rows in rank order."""
-        if self.world == 1:
-            return self.immigrants
+    def all_gather(self) -> None:
+        """all-gather self.mine into self.all (rank order)."""
         try:
             dist.all_gather_into_tensor(self.all, self.mine)
         except (RuntimeError, NotImplementedError):
             parts = list(self.all.chunk(self.world))
             dist.all_gather(parts, self.mine)
+
+    def gather(self) -> torch.Tensor:
+        """all-gather self.mine; returns the other islands' rows in rank order."""
+        if self.world == 1:
+            return self.immigrants
+        self.all_gather()
         lo, hi = self.rank * self.E, (self.rank + 1) * self.E
         self.immigrants[:lo].copy_(self.all[:lo])
         self.immigrants[lo:].copy_(self.all[hi:])
@@ -46,8 +50,8 @@ class IslandExchange:
         if self.world == 1:
             return
         es.pack_elites_device(self.mine.data_ptr(), self.E)
-        imm = self.gather()
-        es.inject_immigrants_device(imm.data_ptr(), self.num_immigrants)
+        self.all_gather()
+        es.inject_gathered_device(self.all.data_ptr(), self.world, self.rank, self.E)
 
     # ---- host path (gloo tests, oracle islands) ---------------------------------------------
     def migrate_host(self, pack, inject) -> None:

@@ -358,6 +358,15 @@ def test_island_rows_roundtrip(pkg, O):
     ref.inject(imm)
     for x, y in zip(es.read_population(), ref.read_population()):
         assert np.array_equal(x, y)
+    # the gathered form: world 4, this island is rank 2 -> blocks 0, 1, 3 are injected
+    import torch
+    allrows = rng.random((4 * 16, 2 * es.D + 1), dtype=np.float32)
+    dev = torch.from_numpy(allrows).cuda()
+    es.inject_gathered_device(dev.data_ptr(), 4, 2, 16)
+    es.synchronize()
+    ref.inject(np.concatenate([allrows[:32], allrows[48:]]))
+    for x, y in zip(es.read_population(), ref.read_population()):
+        assert np.array_equal(x, y)
     es.close()
 
 
