@@ -166,13 +166,21 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
         dk = kernels[dom]
         achieved = dk["alg_bytes_per_candidate"] * P / (dk["avg_us"] * 1e-6) / 1e9
-        traffic = None
+        # measured HBM bytes per launch from the committed rocprofv3 PMC passes (same workload);
+        # only valid for the configuration they were collected on
+        pmc = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and P == 65536 and N == 1024:
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                pmc = json.load(open(tpath))
             except Exception:
-                traffic = None
+                pmc = {}
+        traffic = pmc.get(dom)
+        per_kernel = {}
+        for name, k in kernels.items():
+            a = k["alg_bytes_per_candidate"] * P / (k["avg_us"] * 1e-6) / 1e9
+            per_kernel[name] = {"achieved_GBs_alg": a, "frac_alg": a / HBM_PEAK_GBS, "traffic": pmc.get(name),
+                                "measured_GBs": (pmc[name] / (k["avg_us"] * 1e-6) / 1e9) if name in pmc else None}
         b_alg = 24 * N + 16
         out = {
             "metric": "candidates evaluated/sec (pop x gens / s)",
@@ -193,6 +201,7 @@ def main():
                        "migration_interval": 1, "parallelism": f"island x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" if traffic else None,
                          "avg_kernel_us": dk["avg_us"],
                          "alg_bytes_per_launch": dk["alg_bytes_per_candidate"] * P},
             "pipeline_effective": {"b_alg_bytes_per_candidate": b_alg,
@@ -201,6 +210,7 @@ def main():
                                    "note": "window applied on the FFT kernel's load and the spectrum never materialised: the loop "
                                            "moves 8N bytes per candidate, not B_alg = 24N+16, so this is an effective figure"},
             "kernels": kernels,
+            "roofline_per_kernel": per_kernel,
             "best_fitness_sse": best,
             "best_fitness_mse": best / (N // 2),
         }
