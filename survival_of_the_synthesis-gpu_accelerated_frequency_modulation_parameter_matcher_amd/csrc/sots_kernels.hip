@@ -776,6 +776,12 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // MODE 0: write spectrum rows; MODE 1: accumulate the fitness directly
+// audio rows are read exactly once per generation
+#ifdef SOTS_FFT_NT_LOADS
+#define SOTS_ROW_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SOTS_ROW_LOAD(p) (*(p))
+#endif
 #ifndef SOTS_FFT_MIN_WAVES
 #define SOTS_FFT_MIN_WAVES 1
 #endif
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
     {
         const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)ind * pitch);
 #pragma unroll
-        for (int h = 0; h < Q; ++h) x[h] = in[lane + kWave * h];
+        for (int h = 0; h < Q; ++h) x[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
     }
     while (true) {
         if constexpr (WIN) {
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *
         {
             const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(more ? nxt : ind) * pitch);
 #pragma unroll
-            for (int h = 0; h < Q; ++h) y[h] = in[lane + kWave * h];
+            for (int h = 0; h < Q; ++h) y[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
         }
         fft_forward<M>(x, lds, tw, twr, lane);
         const float2 zh = lds[lds_pad(M / 2)];
@@ -923,6 +929,10 @@ __device__ __forceinline__ uint64_t make_key(float f, uint32_t idx)
     return ((uint64_t)u << 32) | idx;
 }
 
+// Padding slot g >= P of the power-of-two key array: after every real key (NaN included) and
+// unique, which the counting merges rely on.
+__device__ __forceinline__ uint64_t pad_key(uint32_t g) { return 0xFFFFFFFF00000000ull | g; }
+
 __device__ __forceinline__ void cmp_swap(uint64_t &a, uint64_t &b, bool ascending)
 {
     if ((a > b) == ascending) {
@@ -944,7 +954,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const float *__rest
     const uint32_t dir_base = alternate ? base : 0u;
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
         const uint32_t g = base + i;
-        s[i] = g < p_len ? make_key(fitness[g], g) : ~0ull;
+        s[i] = g < p_len ? make_key(fitness[g], g) : pad_key(g);
     }
     __syncthreads();
     for (uint32_t k = 2; k <= tile; k <<= 1) {
@@ -962,6 +972,63 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const float *__rest
         }
     }
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) keys[base + i] = s[i];
+}
+
+// 1024-key tile for the rank merge, without workgroup barriers in the sorting network: each
+// of the four wavefronts bitonic-sorts its own run of 256 keys in its private quarter of the
+// LDS buffer (the LDS operations of one wavefront execute in order, so the 36 steps need no
+// s_barrier), then every key's place in the tile is its index in its own run plus its lower
+// bound in the other three runs (24 LDS reads), the same counting argument as the tile merge.
+constexpr uint32_t kRunKeys = 256;
+
+__global__ __launch_bounds__(256) void k_sort_tiles_1k(const float *__restrict__ fitness,
+                                                       uint64_t *__restrict__ keys, uint32_t p_len)
+{
+    __shared__ uint64_t runs[4 * kRunKeys];
+    __shared__ uint64_t merged[4 * kRunKeys];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t base = blockIdx.x * 4 * kRunKeys + wave * kRunKeys;
+    uint64_t *__restrict__ run = runs + wave * kRunKeys;
+#pragma unroll
+    for (uint32_t r = 0; r < kRunKeys / kWave; ++r) {
+        const uint32_t i = lane + kWave * r, g = base + i;
+        run[i] = g < p_len ? make_key(fitness[g], g) : pad_key(g);
+    }
+    for (uint32_t k = 2; k <= kRunKeys; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (uint32_t r = 0; r < kRunKeys / 2 / kWave; ++r) {
+                const uint32_t t = lane + kWave * r;
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t hi = lo | j;
+                uint64_t a = run[lo], b = run[hi];
+                cmp_swap(a, b, (lo & k) == 0);
+                run[lo] = a;
+                run[hi] = b;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < kRunKeys / kWave; ++r) {
+        const uint32_t i = lane + kWave * r;
+        const uint64_t x = run[i];
+        uint32_t rank = i;
+#pragma unroll
+        for (uint32_t o = 1; o < 4; ++o) {
+            const uint64_t *__restrict__ other = runs + ((wave + o) & 3u) * kRunKeys;
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t step = kRunKeys >> 1; step >= 1; step >>= 1) pos += (other[pos + step - 1] < x) ? step : 0u;
+            rank += pos + ((other[pos] < x) ? 1u : 0u);
+        }
+        merged[rank] = x;
+    }
+    __syncthreads();
+    uint64_t *__restrict__ out = keys + (size_t)blockIdx.x * 4 * kRunKeys;
+    for (uint32_t i = threadIdx.x; i < 4 * kRunKeys; i += 256) out[i] = merged[i];
 }
 
 // One compare-exchange step (k, j) with j >= tile, over the whole padded array.
@@ -1078,7 +1145,7 @@ __global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64
     uint32_t sum = 0;
     for (uint32_t g = quarter; g < groups; g += 4) sum += partial[(size_t)g * n_pad + e];
     part[quarter][j] = sum;
-    if (quarter == 0) src_row[j] = (uint32_t)keys[e]; // 0xffffffff for padding keys
+    if (quarter == 0) src_row[j] = (uint32_t)keys[e]; // >= P for padding keys
     __syncthreads();
     const uint32_t w = 2 * d + 1;
     for (uint32_t t = threadIdx.x; t < kSlots * w; t += kRankThreads) {
@@ -1336,7 +1403,10 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
     uint32_t threads = tile / 2;
     threads = threads < 64 ? 64 : threads > (uint32_t)kSortThreads ? (uint32_t)kSortThreads : threads;
     const bool rank_merge = tiles > 1 && tiles <= kSortMaxTiles;
-    k_sort_tiles<<<tiles, threads, 0, st>>>(fin, keys, p, tile, rank_merge ? 0u : 1u);
+    if (rank_merge && tile == 4 * kRunKeys)
+        k_sort_tiles_1k<<<tiles, 256, 0, st>>>(fin, keys, p);
+    else
+        k_sort_tiles<<<tiles, threads, 0, st>>>(fin, keys, p, tile, rank_merge ? 0u : 1u);
     if (rank_merge) {
         uint16_t *partial = static_cast<uint16_t *>(scratch);
         const uint32_t group = rank_group(tile, tiles), groups = tiles / group;
