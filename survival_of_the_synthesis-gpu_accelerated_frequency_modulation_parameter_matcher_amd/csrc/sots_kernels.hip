@@ -174,6 +174,20 @@ __global__ __launch_bounds__(256) void k_recombine_mutate(const float *__restric
     }
 }
 
+// Audio rows are read exactly once per generation: non-temporal loads keep them from
+// displacing other data in L2 / Infinity Cache (P = 131072: 151 -> 132 us; neutral at 65536).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4 *p)
+{
+    const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#define SOTS_ROW_LOAD(p) nt_load4(p)
+// Row stores of the synthesis kernels stay ordinary: each 128-byte line is assembled in L2 from
+// eight 16-byte stores; a non-temporal store sends every piece to memory (measured 791 us
+// instead of 91 us).
+__device__ __forceinline__ void row_store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
 // ------------------------------------------------------------------------------------
 // synthesisePopulation{,DoubleSeries,TripleParallel}, ocl_program.cl:280-443 /
 // Objective::synthesiseAudio*, Evolutionary_Strategy.hpp:368-495.
@@ -228,7 +242,7 @@ __device__ __forceinline__ void store_block(float *__restrict__ out, const float
     if (active) {
 #pragma unroll
         for (int u = 0; u < kSynthUnroll; u += 4)
-            *reinterpret_cast<float4 *>(out + i + u) = make_float4(y[u], y[u + 1], y[u + 2], y[u + 3]);
+            row_store4(out + i + u, make_float4(y[u], y[u + 1], y[u + 2], y[u + 3]));
     }
 #endif
 }
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(kPairThreads) void k_synth_pair(const float *__rest
 #ifdef SOTS_ABLATE_STORE
                 if (y[0] + y[1] + y[2] + y[3] == 123.456f) out[i] = y[0];
 #else
-                if (carrier && active) *reinterpret_cast<float4 *>(out + i + b) = make_float4(y[0], y[1], y[2], y[3]);
+                if (carrier && active) row_store4(out + i + b, make_float4(y[0], y[1], y[2], y[3]));
 #endif
             }
         }
@@ -776,15 +790,6 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // MODE 0: write spectrum rows; MODE 1: accumulate the fitness directly
-// Audio rows are read exactly once per generation: non-temporal loads keep them from
-// displacing other data in L2 / Infinity Cache (P = 131072: 151 -> 132 us; neutral at 65536).
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load4(const float4 *p)
-{
-    const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-#define SOTS_ROW_LOAD(p) nt_load4(p)
 #ifndef SOTS_FFT_MIN_WAVES
 #define SOTS_FFT_MIN_WAVES 1
 #endif
