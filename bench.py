@@ -29,14 +29,21 @@ sys.path.insert(0, ROOT)
 PKG = "survival_of_the_synthesis-gpu_accelerated_frequency_modulation_parameter_matcher_amd"
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PARAM_MAX = [3520.0, 8.0, 3520.0, 1.0]
-TARGET_PARAMS = [1450.0 / 3520.0, 3.0 / 8.0, 200.0 / 3520.0, 1.0]
+# voice -> (synth kind name, paramMaxs, target parameters in the unit cube)
+VOICES = {
+    "2op": ([3520.0, 8.0, 3520.0, 1.0], [1450.0 / 3520.0, 3.0 / 8.0, 200.0 / 3520.0, 1.0]),
+    "3op_series": ([3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0],
+                   [3078 / 3520.0, 2.0 / 8.0, 3015 / 3520.0, 1.5 / 8.0, 3141 / 3520.0, 1.0 / 8.0]),
+    "4op_series": ([3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0], [0.3, 0.25, 0.85, 0.19, 0.89, 0.125, 0.5, 0.1]),
+    "triple_parallel": ([3520.0, 8.0, 3520.0, 1.0], [0.41, 0.375, 0.057, 1.0, 0.2, 0.5, 0.11, 0.7, 0.6, 0.1, 0.3, 0.4]),
+}
 
 
-def make_target(pkg, log2n, device):
+def make_target(pkg, voice, log2n, device):
     """Target audio from the HIP synthesiser itself (the oracle is not used on the product path)."""
-    es = pkg.HipES(32, 32, pkg.capi.SYNTH_2OP, log2n, None, PARAM_MAX, seed=1, workgroup_size=32, device=device)
-    v = np.tile(np.asarray(TARGET_PARAMS, np.float32), (es.P, 1))
+    pmax, tparams = VOICES[voice]
+    es = pkg.HipES(32, 32, pkg.capi.SYNTH_NAMES[voice], log2n, None, pmax, seed=1, workgroup_size=32, device=device)
+    v = np.tile(np.asarray(tparams, np.float32), (es.P, 1))
     es.write_population(v, np.full_like(v, 0.1), None)
     es.synthesise()
     audio = es.read_audio()[0].copy()
@@ -44,12 +51,14 @@ def make_target(pkg, log2n, device):
     return audio
 
 
-def cpu_baseline(log2n, target_audio, budget_s=12.0):
+def cpu_baseline(voice, log2n, target_audio, budget_s=12.0):
     """The CPU oracle (oracle/sots_oracle.c, a single-threaded port of the reference's
     Evolutionary_Strategy_CPU path) timed on this host on a bounded sample of the workload."""
     from oracle import oracle as O
     parents, offspring = 512, 1536
-    ref = O.OracleES(parents, offspring, O.SYNTH_2OP, log2n, None, PARAM_MAX, seed=0x5EED0001, recomb_block=32)
+    kind = {"2op": O.SYNTH_2OP, "3op_series": O.SYNTH_3OP_SERIES, "4op_series": O.SYNTH_4OP_SERIES,
+            "triple_parallel": O.SYNTH_TRIPLE_PAR}[voice]
+    ref = O.OracleES(parents, offspring, kind, log2n, None, VOICES[voice][0], seed=0x5EED0001, recomb_block=32)
     ref.set_target_audio(target_audio)
     ref.init_population(0)
     t0 = time.perf_counter()
@@ -62,7 +71,7 @@ def cpu_baseline(log2n, target_audio, budget_s=12.0):
     dt = time.perf_counter() - t0
     p = parents + offspring
     return {"value": p * gens / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
-            "sample": f"pop={p} x {gens} generations, 2-op FM, N={1 << log2n}, fp64 built-in FFT "
+            "sample": f"pop={p} x {gens} generations, {voice} FM, N={1 << log2n}, fp64 built-in FFT "
                       f"(FFTW unavailable), {dt:.1f} s on 1 core"}
 
 
@@ -75,6 +84,7 @@ def main():
     ap.add_argument("--offspring", type=int, default=49152)
     ap.add_argument("--log2n", type=int, default=10)
     ap.add_argument("--elites", type=int, default=16)
+    ap.add_argument("--synth", default="2op", choices=sorted(VOICES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --share-gpu rehearses N > 1 on a 1-GPU box")
@@ -107,8 +117,8 @@ def main():
     pkg = importlib.import_module(PKG)
     P = args.parents + args.offspring
     N = 1 << args.log2n
-    target = make_target(pkg, args.log2n, local_rank)
-    es = pkg.HipES(args.parents, args.offspring, pkg.capi.SYNTH_2OP, args.log2n, None, PARAM_MAX,
+    target = make_target(pkg, args.synth, args.log2n, local_rank)
+    es = pkg.HipES(args.parents, args.offspring, pkg.capi.SYNTH_NAMES[args.synth], args.log2n, None, VOICES[args.synth][0],
                    seed=0x5EED0001, workgroup_size=32, device=local_rank, gid_base=rank * P,
                    num_generations=args.steps)
     stream = torch.cuda.Stream(device=device)
@@ -195,7 +205,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: pop={P} ({args.parents}+{args.offspring}) per GPU, 2-op FM, "
+            "config": {"workload": f"{'BASELINE configs[2]: ' if (P, N, args.synth) == (65536, 1024, '2op') else ''}pop={P} ({args.parents}+{args.offspring}) per GPU, {args.synth} FM, "
                                    f"{N}-sample / {N}-pt FFT, fp32",
                        "islands": world, "elites_per_island": args.elites if world > 1 else 0,
                        "migration_interval": 1, "parallelism": f"island x{world}"},
@@ -215,7 +225,7 @@ def main():
             "best_fitness_mse": best / (N // 2),
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.log2n, target)
+            cb = cpu_baseline(args.synth, args.log2n, target)
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -205,7 +205,6 @@ __device__ __forceinline__ void row_store4(float *p, float4 v) { *reinterpret_ca
 //                  ahead of the table reads that hang off them.
 // Both follow the per-sample operation order of the reference exactly.
 // ------------------------------------------------------------------------------------
-constexpr int kSynthThreads = 256;     // smallest workgroup: one wavefront per SIMD
 constexpr int kSynthMaxThreads = 1024; // largest: four per SIMD
 constexpr int kSynthUnroll = 8;
 constexpr float kWf = (float)kWavetableSize;
@@ -287,7 +286,8 @@ __global__ __launch_bounds__(kPairThreads) void k_synth_pair(const float *__rest
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const bool carrier = lane >= 32;
 
-    for (uint32_t base = blockIdx.x * kPairIndividuals; base < p_len; base += gridDim.x * kPairIndividuals) {
+    const uint32_t per_block = blockDim.x / 2; // individuals per workgroup
+    for (uint32_t base = blockIdx.x * per_block; base < p_len; base += gridDim.x * per_block) {
         const uint32_t slot_id = base + wave * 32 + (lane & 31);
         const bool active = slot_id < p_len; // all lanes keep running (the swap crosses lanes)
         const uint32_t ind = active ? slot_id : p_len - 1u;
@@ -1280,11 +1280,13 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     }();
     if (kind == SOTS_SYNTH_2OP && SOTS_SYNTH_PAIR && use_pair && share <= (uint32_t)kPairIndividuals) {
         // small share: two lanes per individual double the wavefronts per SIMD
-        k_synth_pair<<<grid_for(p, kPairIndividuals, cus), kPairThreads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
+        uint32_t per_block = ((share + 31) / 32) * 32;
+        per_block = per_block < 32 ? 32 : per_block;
+        k_synth_pair<<<grid_for(p, per_block, cus), 2 * per_block, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
         return hipGetLastError();
     }
     uint32_t threads = ((share + kWave - 1) / kWave) * kWave;
-    threads = threads < (uint32_t)kSynthThreads ? (uint32_t)kSynthThreads : threads > (uint32_t)kSynthMaxThreads ? (uint32_t)kSynthMaxThreads : threads;
+    threads = threads < (uint32_t)kWave ? (uint32_t)kWave : threads > (uint32_t)kSynthMaxThreads ? (uint32_t)kSynthMaxThreads : threads;
     const uint32_t grid = grid_for(p, threads, cus);
     switch (kind) {
     case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
