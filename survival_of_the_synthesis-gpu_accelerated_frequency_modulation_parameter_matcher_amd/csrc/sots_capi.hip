@@ -548,6 +548,7 @@ int sots_stage_sort(sots_ctx *ctx)
 int sots_stage_rotate(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = bind_device(ctx)) return rc;
     // rotationIndex_ flip, ...OpenCL.hpp:486; a kernel argument here, so no transfer
     StageScope t(ctx, SOTS_STAGE_ROTATE);
     ctx->rot ^= 1u;
