@@ -1,0 +1,75 @@
+"""CPU tests of the C++ host layer (host/Evolutionary_Strategy.hpp, Benchmarker.hpp,
+CSV_Logger.hpp): compiled with g++ here, no GPU and no libsots_hip involved, compared with the
+CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "survival_of_the_synthesis-gpu_accelerated_frequency_modulation_parameter_matcher_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def run(tmp_path_factory):
+    d = tmp_path_factory.mktemp("hostcpu")
+    exe = d / "host_cpu_test"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-parameter",
+                           "-o", str(exe), os.path.join(HOST, "host_cpu_test.cpp")])
+    out = subprocess.run([str(exe), str(d)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return d, out.stdout
+
+
+def f32(d, name):
+    return np.fromfile(d / name, np.float32)
+
+
+def test_objective_matches_the_oracle(run, O):
+    d, text = run
+    assert np.array_equal(f32(d, "wavetable.f32"), O.wavetable())
+    w64, wf = O.window(1024)
+    assert np.array_equal(f32(d, "window.f32"), w64.astype(np.float32))
+    p2 = [3520.0, 8.0, 3520.0, 1.0]
+    a = O.synth(0, [0.411931818, 0.375, 0.0568181818, 1.0], [0.0] * 4, p2, 1024)
+    assert np.array_equal(f32(d, "voice2.f32"), a)
+    # fp64 FFTs of different construction: equal to the last fp32 bit of the peak
+    np.testing.assert_allclose(f32(d, "voice2_mag.f32"), O.spectrum(a), rtol=0, atol=np.spacing(np.float32(0.25)))
+    # phases restart on every call (the reference carries them over, Evolutionary_Strategy.hpp:178-180)
+    assert np.array_equal(f32(d, "voice2b.f32"), O.synth(0, [0.9, 1.0, 0.02, 0.5], [0.0] * 4, p2, 1024))
+    assert np.array_equal(f32(d, "voice6.f32"),
+                          O.synth(1, [3078 / 3520, 2 / 8, 3015 / 3520, 1.5 / 8, 3141 / 3520, 1 / 8], [0.0] * 6,
+                                  [3520.0, 8.0] * 3, 1024))
+    assert np.array_equal(f32(d, "voice8.f32"),
+                          O.synth(3, [0.3, 0.25, 0.85, 0.19, 0.89, 0.125, 0.5, 0.1], [0.0] * 8, [3520.0, 8.0] * 4, 1024))
+    assert np.array_equal(f32(d, "voice12.f32"),
+                          O.synth(2, [0.41, 0.375, 0.057, 1.0, 0.2, 0.5, 0.11, 0.7, 0.6, 0.1, 0.3, 0.4], [0.0] * 4, p2, 1024))
+    line = [l for l in text.splitlines() if l.startswith("scale")][0].split()
+    assert [float(x) for x in line[1:5]] == [1760.0, 2.0, 3520.0, 0.0]
+    assert float(line[6]) == 1.0 and int(line[8]) == 1024 + 8
+
+
+def test_population_sort_is_stable_and_constants(run):
+    _, text = run
+    line = [l for l in text.splitlines() if l.startswith("order")][0].split()
+    # fitness 3,1,NaN,1,0,-0,2,1 -> 0 and -0 tie (index order), the three 1s keep their order, NaN last
+    assert [int(float(x)) for x in line[1:9]] == [4, 5, 1, 3, 7, 6, 0, 2]
+    alpha, inv, rtop, bscale, beta = [float(x) for x in line[10:15]]
+    assert alpha == np.float32(1.4) and inv == np.float32(1.0) / np.float32(1.4)
+    assert rtop == np.sqrt(np.float32(2.0) / np.float32(np.pi)) and bscale == 0.5 and beta == np.sqrt(np.float32(0.5))
+
+
+def test_benchmarker_and_csv(run):
+    d, text = run
+    assert "counts 3 0 total 9.000" in text and "after 0" in text and "reject 0 accept 1" in text
+    rows = (d / "bench.csv").read_text().strip().splitlines()
+    assert rows[0] == "Test_Name,Total_Time,Average_Time,Max_Time,Min_Time,Max_Difference,Average_Difference,"
+    a = rows[1].rstrip(",").split(",")
+    assert a[0] == "stageA" and [float(x) for x in a[1:5]] == [9.0, 3.0, 4.0, 2.0]
+    # differences between consecutive samples: |2-0|, |4-2|, |3-4| -> max 2, mean 5/3
+    assert float(a[5]) == 2.0 and abs(float(a[6]) - 5.0 / 3.0) < 1e-6
+    once = rows[2].rstrip(",").split(",")
+    assert once[0] == "once" and len(once) == 7 and float(once[2]) == 7.5
+    assert rows[3].startswith("wall,")
+    assert (d / "raw.csv").read_text() == "a,b,\n1,2,\n"
