@@ -790,14 +790,11 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // MODE 0: write spectrum rows; MODE 1: accumulate the fitness directly
-#ifndef SOTS_FFT_MIN_WAVES
-#define SOTS_FFT_MIN_WAVES 1
-#endif
 // WIN: multiply by the fp32 window while loading (the generation loop then skips both the
 // window pass and any window work in the synthesis kernel; the product is the same single
 // fp32 rounding either way).
 template <int LOG2N, int MODE, bool WIN>
-__global__ __launch_bounds__(kWave, SOTS_FFT_MIN_WAVES) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
+__global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
                                                const float2 *__restrict__ tw, const float *__restrict__ window,
                                                uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
@@ -1261,10 +1258,6 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
     return hipGetLastError();
 }
 
-#ifndef SOTS_SYNTH_PAIR
-#define SOTS_SYNTH_PAIR 1
-#endif
-
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
                         uint32_t num_cus)
@@ -1275,10 +1268,10 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     // of the population: more wavefronts per SIMD hide more of the table-read and store latency.
     const uint32_t share = (p + cus - 1) / cus;
     static const bool use_pair = [] {
-        const char *e = getenv("SOTS_SYNTH_PAIR");
+        const char *e = getenv("SOTS_SYNTH_PAIR"); // 0: always the one-lane-per-individual kernel (A/B profiling)
         return e ? atoi(e) != 0 : true;
     }();
-    if (kind == SOTS_SYNTH_2OP && SOTS_SYNTH_PAIR && use_pair && share <= (uint32_t)kPairIndividuals) {
+    if (kind == SOTS_SYNTH_2OP && use_pair && share <= (uint32_t)kPairIndividuals) {
         // small share: two lanes per individual double the wavefronts per SIMD
         uint32_t per_block = ((share + 31) / 32) * 32;
         per_block = per_block < 32 ? 32 : per_block;

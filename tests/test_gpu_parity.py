@@ -118,6 +118,22 @@ def test_synthesise_bitexact(pkg, O, kind, log2n):
     es.close()
 
 
+def test_synthesise_two_op_large_population_uses_lane_per_individual_kernel(pkg, O):
+    """Above 256 individuals per CU the 2-op voice runs k_synth (software-pipelined, one lane per
+    individual) instead of the lane-pair kernel; rows are spot-checked against the oracle."""
+    parents, offspring = 16640, 49920          # P = 66560 = 260 per CU on 256 CUs
+    es, _ = make_pair(pkg, O, parents, offspring, 0, 10)
+    es.init_population(0)
+    v, s, _ = es.read_population()
+    es.synthesise()
+    audio = es.read_audio()
+    rng = np.random.default_rng(17)
+    rows = np.concatenate([[0, 1, 63, 64, 319, 320, es.P - 1], rng.choice(es.P, 200, replace=False)])
+    for r in rows:
+        assert np.array_equal(audio[r], O.synth(0, v[r], [0.0] * 4, PMAX[0], es.N)), f"row {r}"
+    es.close()
+
+
 def test_synthesise_nonzero_param_min(pkg, O):
     pmin = [100.0, 0.5, 50.0, 0.1]
     es, ref = make_pair(pkg, O, 32, 32, 0, 10, pmin=pmin)
