@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--log2n", type=int, default=10)
     ap.add_argument("--elites", type=int, default=16)
     ap.add_argument("--synth", default="2op", choices=sorted(VOICES))
+    ap.add_argument("--sync-migration", action="store_true",
+                    help="inject elites inside the generation that gathered them (default: the all-gather "
+                         "overlaps the next generation and its rows arrive one generation later)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --share-gpu rehearses N > 1 on a 1-GPU box")
@@ -124,7 +127,7 @@ def main():
     stream = torch.cuda.Stream(device=device)
     es.set_stream(stream.cuda_stream)
     es.set_target_audio(target)
-    island = pkg.island.IslandExchange(rank, world, args.elites, es.D, device)
+    island = pkg.island.IslandExchange(rank, world, args.elites, es.D, device, overlap=not args.sync_migration)
 
     def step():
         es.execute_generations(1)
@@ -148,6 +151,7 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
+        island.finish()
     es.timing_enable(False)
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -208,7 +212,9 @@ def main():
             "config": {"workload": f"{'BASELINE configs[2]: ' if (P, N, args.synth) == (65536, 1024, '2op') else ''}pop={P} ({args.parents}+{args.offspring}) per GPU, {args.synth} FM, "
                                    f"{N}-sample / {N}-pt FFT, fp32",
                        "islands": world, "elites_per_island": args.elites if world > 1 else 0,
-                       "migration_interval": 1, "parallelism": f"island x{world}"},
+                       "migration_interval": 1,
+                       "migration": "none" if world == 1 else ("same generation" if args.sync_migration else "overlapped, arrives one generation later"),
+                       "parallelism": f"island x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" if traffic else None,

@@ -12,7 +12,7 @@ PKG = "survival_of_the_synthesis-gpu_accelerated_frequency_modulation_parameter_
 
 
 def main():
-    out_dir, gens, elites = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    out_dir, gens, elites, overlap = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) != 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     island_mod = importlib.import_module(PKG + ".island")
@@ -24,12 +24,13 @@ def main():
     es = O.OracleES(parents, offspring, O.SYNTH_2OP, 10, None, pmax, seed=0x5EED0001, recomb_block=32, gid_base=rank * P)
     es.set_target_audio(O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, pmax, 1024))
     es.init_population(0)
-    ex = island_mod.IslandExchange(rank, world, elites, es.D, "cpu")
+    ex = island_mod.IslandExchange(rank, world, elites, es.D, "cpu", overlap=overlap)
     sent = []
     for _ in range(gens):
         es.generation()
         sent.append(es.pack_elites(elites))
         ex.migrate_host(es.pack_elites, es.inject)
+    ex.finish()
     v, s, f = es.read_population()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=v, s=s, f=f, sent=np.stack(sent))
     dist.barrier()

@@ -18,7 +18,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def simulate(O, world, gens, elites):
+def simulate(O, world, gens, elites, overlap):
     pmax = [3520.0, 8.0, 3520.0, 1.0]
     tgt = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, pmax, 1024)
     isl = []
@@ -27,17 +27,24 @@ def simulate(O, world, gens, elites):
         es.set_target_audio(tgt)
         es.init_population(0)
         isl.append(es)
+    in_flight = None  # overlap schedule: elites gathered after generation g arrive after g+1
     for _ in range(gens):
         for es in isl:
             es.generation()
+        if overlap and in_flight is not None:
+            for r, es in enumerate(isl):
+                es.inject(np.concatenate([in_flight[q] for q in range(world) if q != r]))
         packs = [es.pack_elites(elites) for es in isl]
-        for r, es in enumerate(isl):
-            es.inject(np.concatenate([packs[q] for q in range(world) if q != r]))
+        if overlap:
+            in_flight = packs
+        else:
+            for r, es in enumerate(isl):
+                es.inject(np.concatenate([packs[q] for q in range(world) if q != r]))
     return [es.read_population() for es in isl]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_island_exchange_over_gloo(tmp_path, O, world):
+@pytest.mark.parametrize("world,overlap", [(2, 0), (3, 0), (2, 1), (3, 1)])
+def test_island_exchange_over_gloo(tmp_path, O, world, overlap):
     gens, elites = 4, 4
     port = free_port()
     procs = []
@@ -45,20 +52,21 @@ def test_island_exchange_over_gloo(tmp_path, O, world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_island_worker.py"),
-                                       str(tmp_path), str(gens), str(elites)], env=env,
+                                       str(tmp_path), str(gens), str(elites), str(overlap)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out.decode()
-    want = simulate(O, world, gens, elites)
+    want = simulate(O, world, gens, elites, overlap)
     got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for r in range(world):
         assert np.array_equal(got[r]["v"], want[r][0])
         assert np.array_equal(got[r]["s"], want[r][1])
         assert np.array_equal(got[r]["f"], want[r][2])
-    # every island's parent tail holds the other islands' last elites, in rank order
+    # every island's parent tail holds the other islands' elites, in rank order: the last ones sent,
+    # or with the overlap schedule those of the generation before
     for r in range(world):
-        others = np.concatenate([got[q]["sent"][-1] for q in range(world) if q != r])
+        others = np.concatenate([got[q]["sent"][-2 if overlap else -1] for q in range(world) if q != r])
         n = others.shape[0]
         assert np.array_equal(got[r]["f"][32 - n:32], others[:, 0])
         assert np.array_equal(got[r]["v"][32 - n:32], others[:, 1:5])
@@ -67,7 +75,9 @@ def test_island_exchange_over_gloo(tmp_path, O, world):
 
 
 def test_single_island_is_a_no_op(O, pkg):
-    ex = pkg.island.IslandExchange(0, 1, 4, 4, "cpu")
-    calls = []
-    ex.migrate_host(lambda n: calls.append(n), lambda rows: calls.append(rows))
-    assert calls == [] and ex.num_immigrants == 0
+    for overlap in (False, True):
+        ex = pkg.island.IslandExchange(0, 1, 4, 4, "cpu", overlap=overlap)
+        calls = []
+        ex.migrate_host(lambda n: calls.append(n), lambda rows: calls.append(rows))
+        ex.finish()
+        assert calls == [] and ex.num_immigrants == 0
