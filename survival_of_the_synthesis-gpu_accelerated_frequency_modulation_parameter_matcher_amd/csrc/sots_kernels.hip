@@ -219,8 +219,28 @@ __device__ __forceinline__ float tab_at(const float *tab, float pos)
     return tab[i];
 #endif
 }
-__device__ __forceinline__ void wrap_hi(float &p) { if (p >= kWf) p -= kWf; }
-__device__ __forceinline__ void wrap_lo(float &p) { if (p < 0.0f) p += kWf; }
+// The reference's two conditional wraps, `if (p >= W) p -= W;` and `if (p < 0) p += W;`, as
+// subtract/add and an UNSIGNED INTEGER minimum of the bit patterns.  Non-negative floats order
+// like their bit patterns and every negative float is a larger unsigned number than every
+// non-negative one.  The subtraction and addition are the reference's own fp32 operations, so
+// the result carries its rounding.
+//   wrap_hi (first wrap only, 2 instructions instead of 3): p >= W -> 0 <= p-W < p picks p-W;
+//     0 <= p < W -> p-W < 0 picks p;  p < 0 -> p-W is further from zero than p, picks p.
+//   wrap_both (both wraps, 3 instructions instead of 6, and the phase recurrence becomes
+//     add -> {sub, add} -> v_min3_u32):  p >= W -> the reference takes p-W, which is >= 0 so its
+//     second wrap does nothing, and p-W is the smallest pattern;  0 <= p < W -> it keeps p, p-W
+//     is negative and p+W larger;  p < 0 -> it takes p+W, which is non-negative or closer to
+//     zero than p and p-W.
+// The one bit pattern that would differ is p == -0.0f in wrap_both (the reference keeps it, this
+// gives W): a phase starts at +0.0f and x + y is -0.0f only when both are, so it never occurs.
+__device__ __forceinline__ void wrap_hi(float &p)
+{
+    p = __uint_as_float(min(__float_as_uint(p - kWf), __float_as_uint(p)));
+}
+__device__ __forceinline__ void wrap_both(float &p)
+{
+    p = __uint_as_float(min(min(__float_as_uint(p - kWf), __float_as_uint(p + kWf)), __float_as_uint(p)));
+}
 
 __device__ __forceinline__ void load_wavetable(float *__restrict__ tab, const float *__restrict__ wavetable)
 {
@@ -267,8 +287,7 @@ __device__ __forceinline__ float pair_step(const float *tab, float &pos, float &
     slot = tab_at(tab, pos);
     const float cur = x * mul_l + add_l;
     pos += c * cur;
-    wrap_hi(pos);
-    wrap_lo(pos); // never taken for the modulator chain (its phase only grows)
+    wrap_both(pos);
     // keep this step's table request inside the step: left alone, the scheduler sinks the four
     // requests of an unrolled iteration to its end and their latency is exposed again
     __builtin_amdgcn_sched_barrier(0);
@@ -340,6 +359,254 @@ __global__ __launch_bounds__(kPairThreads) void k_synth_pair(const float *__rest
     }
 }
 
+// ---- 2-operator voice, one lane per individual, whole-line stores through LDS -------------
+// EXPERIMENT (SOTS_SYNTH_STAGED=1).  Four wavefronts, each with a private 8 KiB tile
+// [64 rows][8 chunks of 16 B], XOR-swizzled by row so that both the row-wise writes (lane =
+// row) and the transposed reads (lane = 8 rows x 8 chunks) are bank-conflict free.  Every 32
+// samples the tile is read back transposed and written with stores in which 8 neighbouring
+// lanes cover one whole 128-byte line of one row.
+constexpr int kStagedThreads = 256;
+constexpr int kStageChunks = 8; // 16-byte chunks per row per flush = 32 samples
+
+__global__ __launch_bounds__(kStagedThreads) void k_synth_staged(const float *__restrict__ values,
+                                                                 const float *__restrict__ wavetable,
+                                                                 float *__restrict__ audio, SynthParams sp,
+                                                                 uint32_t p_len, uint32_t n, uint32_t pitch)
+{
+    __shared__ float tab[kWavetableSize];
+    __shared__ float4 stage_all[(kStagedThreads / kWave) * kWave * kStageChunks];
+    load_wavetable(tab, wavetable);
+    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
+    // write side: lane = row; chunk c of the row lives in slot c ^ (row & 7)
+    float4 *__restrict__ wr = stage + lane * kStageChunks;
+    const uint32_t l7 = lane & 7u;
+    // read side: lane = (row & 7 within a group of 8 rows, chunk): group `it` adds 64 slots
+    const uint32_t r8 = lane >> 3;
+    const float4 *__restrict__ rd = stage + r8 * kStageChunks + (l7 ^ r8);
+    const uint32_t lane_off = r8 * pitch + 4u * l7; // floats, relative to the group's first row
+
+    for (uint32_t base = blockIdx.x * kStagedThreads; base < p_len; base += gridDim.x * kStagedThreads) {
+        const uint32_t row0 = base + wave * kWave; // first row of this wavefront
+        const bool active = row0 + lane < p_len;
+        const uint32_t ind = active ? row0 + lane : p_len - 1u;
+        const float4 v = *reinterpret_cast<const float4 *>(values + (size_t)ind * 4);
+        const float p0 = sp.pmin[0] + v.x * (sp.pmax[0] - sp.pmin[0]);
+        const float p1 = sp.pmin[1] + v.y * (sp.pmax[1] - sp.pmin[1]);
+        const float fc = sp.pmin[2] + v.z * (sp.pmax[2] - sp.pmin[2]);
+        const float amp = sp.pmin[3] + v.w * (sp.pmax[3] - sp.pmin[3]);
+        const float mod = p0 * p1, inc1 = c * p0;
+        const bool full = row0 + kWave <= p_len; // every row of the tile exists
+        float pos1 = 0.0f, pos2 = 0.0f;
+        // Two register sets (a, b) alternate so that no block is ever copied: while block k's
+        // carrier reads land in one set, block k-1's results leave from the other.
+        float ta[kSynthUnroll], tb[kSynthUnroll], ya[kSynthUnroll], yb[kSynthUnroll];
+        auto modulator = [&](float (&t)[kSynthUnroll]) { // stage A: table reads of the next block
+#pragma unroll
+            for (int u = 0; u < kSynthUnroll; ++u) {
+                t[u] = tab_at(tab, pos1);
+                pos1 += inc1;
+                wrap_hi(pos1);
+            }
+        };
+        auto carrier = [&](const float (&t)[kSynthUnroll], float (&y)[kSynthUnroll]) { // stage B
+#pragma unroll
+            for (int u = 0; u < kSynthUnroll; ++u) {
+                const float cur = t[u] * mod + fc;
+                y[u] = tab_at(tab, pos2);
+                pos2 += c * cur;
+                wrap_both(pos2);
+            }
+        };
+        auto emit = [&](const float (&y)[kSynthUnroll], uint32_t ip) { // stage C: samples ip..ip+7
+            const uint32_t c0 = (ip >> 2) & (kStageChunks - 1);
+            wr[c0 ^ l7] = make_float4(y[0] * amp, y[1] * amp, y[2] * amp, y[3] * amp);
+            wr[(c0 + 1) ^ l7] = make_float4(y[4] * amp, y[5] * amp, y[6] * amp, y[7] * amp);
+            if (c0 == kStageChunks - 2) { // 32 samples parked: flush the tile
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                const uint32_t i0 = ip + kSynthUnroll - 4 * kStageChunks;
+                float *__restrict__ grp = audio + (size_t)row0 * pitch + i0 + lane_off;
+                if (full) {
+                    constexpr int G = 8 * kStageChunks; // slots per group of 8 rows
+                    const float4 q0 = rd[0 * G], q1 = rd[1 * G], q2 = rd[2 * G], q3 = rd[3 * G];
+                    const float4 q4 = rd[4 * G], q5 = rd[5 * G], q6 = rd[6 * G], q7 = rd[7 * G];
+                    const size_t g8 = (size_t)8u * pitch;
+                    *reinterpret_cast<float4 *>(grp + 0 * g8) = q0;
+                    *reinterpret_cast<float4 *>(grp + 1 * g8) = q1;
+                    *reinterpret_cast<float4 *>(grp + 2 * g8) = q2;
+                    *reinterpret_cast<float4 *>(grp + 3 * g8) = q3;
+                    *reinterpret_cast<float4 *>(grp + 4 * g8) = q4;
+                    *reinterpret_cast<float4 *>(grp + 5 * g8) = q5;
+                    *reinterpret_cast<float4 *>(grp + 6 * g8) = q6;
+                    *reinterpret_cast<float4 *>(grp + 7 * g8) = q7;
+                } else { // last, partly filled tile of the population
+#pragma unroll 1
+                    for (uint32_t it = 0; it < kWave / 8; ++it)
+                        if (row0 + 8u * it + r8 < p_len)
+                            *reinterpret_cast<float4 *>(grp + (size_t)(8u * it) * pitch) = rd[it * 8 * kStageChunks];
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+            }
+        };
+        modulator(ta);
+        for (uint32_t i = 0; i < n; i += 2 * kSynthUnroll) { // n is a multiple of 16 (n >= 512)
+            modulator(tb);
+            carrier(ta, ya);
+            if (i > 0) emit(yb, i - kSynthUnroll);
+            if (i + 2 * kSynthUnroll < n) modulator(ta);
+            carrier(tb, yb);
+            emit(ya, i);
+        }
+        emit(yb, n - kSynthUnroll);
+    }
+}
+
+// ---- 2-operator voice, a modulator wavefront and a carrier wavefront per 64 individuals ------
+// EXPERIMENT (SOTS_SYNTH_DUO=1).  The modulator phase never depends on the carrier, so the
+// two recurrences run in different wavefronts: the HELPER advances the modulator phase, reads
+// the table and hands c * (t * mod + fc) - the carrier's phase increment - over through LDS,
+// eight samples at a time; the CARRIER advances its phase, reads the table, scales and parks
+// the samples in a swizzled [64 rows][16 samples] tile that it flushes with stores in which four
+// neighbouring lanes cover 64 contiguous bytes of one row.  Each per-sample operation is the
+// reference's, in its order, so the result is bit-identical to k_synth<2OP>.
+constexpr int kDuoMaxPairs = 4;                // carrier/helper pairs per workgroup
+constexpr int kDuoBlock = 8;                   // samples per hand-over
+constexpr int kDuoTileChunks = 4;              // 16-byte chunks per staged row (16 samples)
+
+__global__ __launch_bounds__(kDuoMaxPairs * 2 * kWave) void k_synth_duo(const float *__restrict__ values,
+                                                                         const float *__restrict__ wavetable,
+                                                                         float *__restrict__ audio, SynthParams sp,
+                                                                         uint32_t p_len, uint32_t n, uint32_t pitch)
+{
+    __shared__ float tab[kWavetableSize];
+    __shared__ float4 xinc_all[kDuoMaxPairs][2][kDuoBlock / 4][kWave]; // 4 KiB per pair
+    __shared__ float4 tile_all[kDuoMaxPairs][kWave * kDuoTileChunks];   // 4 KiB per pair
+    load_wavetable(tab, wavetable);
+    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
+    const uint32_t pairs = blockDim.x / (2 * kWave);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const bool helper = wave >= pairs;
+    const uint32_t pair = helper ? wave - pairs : wave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    float4(*__restrict__ xinc)[kDuoBlock / 4][kWave] = xinc_all[pair];
+    float4 *__restrict__ tile = tile_all[pair];
+    // tile write side: lane = row, chunk q of the row in slot q ^ ((row >> 1) & 3) (conflict-free
+    // for the 8-lane groups of ds_write_b128 on a 64-byte row); read side: lane = (row & 15, chunk)
+    float4 *__restrict__ wr = tile + lane * kDuoTileChunks;
+    const uint32_t wswz = (lane >> 1) & 3u;
+    const uint32_t r16 = lane >> 2, ch = lane & 3u;
+    const float4 *__restrict__ rd = tile + r16 * kDuoTileChunks + (ch ^ ((r16 >> 1) & 3u));
+    const uint32_t lane_off = r16 * pitch + 4u * ch;
+
+    for (uint32_t base = blockIdx.x * pairs * kWave; base < p_len; base += gridDim.x * pairs * kWave) {
+        const uint32_t row0 = base + pair * kWave;
+        const uint32_t ind = row0 + lane < p_len ? row0 + lane : p_len - 1u;
+        const float4 v = *reinterpret_cast<const float4 *>(values + (size_t)ind * 4);
+        const float p0 = sp.pmin[0] + v.x * (sp.pmax[0] - sp.pmin[0]);
+        const float p1 = sp.pmin[1] + v.y * (sp.pmax[1] - sp.pmin[1]);
+        const float fc = sp.pmin[2] + v.z * (sp.pmax[2] - sp.pmin[2]);
+        const float amp = sp.pmin[3] + v.w * (sp.pmax[3] - sp.pmin[3]);
+        const float mod = p0 * p1, inc1 = c * p0;
+        const bool full = row0 + kWave <= p_len;
+        float pos = 0.0f; // the helper's modulator phase or the carrier's phase
+        float ta[kDuoBlock], tb[kDuoBlock];
+
+        auto gather = [&](float (&t)[kDuoBlock]) { // helper: table reads of one block
+#pragma unroll
+            for (int u = 0; u < kDuoBlock; ++u) {
+                t[u] = tab_at(tab, pos);
+                pos += inc1;
+                wrap_hi(pos);
+            }
+        };
+        auto hand_over = [&](const float (&t)[kDuoBlock], uint32_t buf) { // helper: increments of one block
+#pragma unroll
+            for (int j = 0; j < kDuoBlock / 4; ++j) {
+                float4 q;
+                q.x = c * (t[4 * j + 0] * mod + fc);
+                q.y = c * (t[4 * j + 1] * mod + fc);
+                q.z = c * (t[4 * j + 2] * mod + fc);
+                q.w = c * (t[4 * j + 3] * mod + fc);
+                xinc[buf][j][lane] = q;
+            }
+        };
+        auto advance = [&](float (&y)[kDuoBlock], uint32_t buf) { // carrier: one block of the recurrence
+            float inc[kDuoBlock];
+#pragma unroll
+            for (int j = 0; j < kDuoBlock / 4; ++j) {
+                const float4 q = xinc[buf][j][lane];
+                inc[4 * j + 0] = q.x, inc[4 * j + 1] = q.y, inc[4 * j + 2] = q.z, inc[4 * j + 3] = q.w;
+            }
+#pragma unroll
+            for (int u = 0; u < kDuoBlock; ++u) {
+                y[u] = tab_at(tab, pos);
+                pos += inc[u];
+                wrap_both(pos);
+            }
+        };
+        auto emit = [&](const float (&y)[kDuoBlock], uint32_t ip) { // carrier: samples ip..ip+7 leave
+            const uint32_t c0 = (ip >> 2) & (kDuoTileChunks - 1);
+            wr[c0 ^ wswz] = make_float4(y[0] * amp, y[1] * amp, y[2] * amp, y[3] * amp);
+            wr[(c0 + 1) ^ wswz] = make_float4(y[4] * amp, y[5] * amp, y[6] * amp, y[7] * amp);
+            if (c0 == kDuoTileChunks - 2) { // 16 samples parked: flush the tile
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                const uint32_t i0 = ip + kDuoBlock - 4 * kDuoTileChunks;
+                float *__restrict__ grp = audio + (size_t)row0 * pitch + i0 + lane_off;
+                constexpr int G = 16 * kDuoTileChunks; // slots per group of 16 rows
+                const size_t g16 = (size_t)16u * pitch;
+                if (full) {
+                    const float4 q0 = rd[0 * G], q1 = rd[1 * G], q2 = rd[2 * G], q3 = rd[3 * G];
+                    *reinterpret_cast<float4 *>(grp + 0 * g16) = q0;
+                    *reinterpret_cast<float4 *>(grp + 1 * g16) = q1;
+                    *reinterpret_cast<float4 *>(grp + 2 * g16) = q2;
+                    *reinterpret_cast<float4 *>(grp + 3 * g16) = q3;
+                } else { // last, partly filled tile of the population
+#pragma unroll 1
+                    for (uint32_t it = 0; it < 4; ++it)
+                        if (row0 + 16u * it + r16 < p_len) *reinterpret_cast<float4 *>(grp + it * g16) = rd[it * G];
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+            }
+        };
+
+        // Step k: the helper hands over block k+1 (read from the table during step k-1) and
+        // reads the table for block k+2; the carrier advances block k and sends block k-1 out.
+        // Register sets a/b alternate, so the loop body covers two blocks.  n is a multiple of 16.
+        if (helper) {
+            gather(ta);
+            hand_over(ta, 0);
+            gather(tb);
+        }
+        __syncthreads();
+        for (uint32_t i = 0; i < n; i += 2 * kDuoBlock) {
+            if (helper) {
+                hand_over(tb, 1);                              // block k+1
+                if (i + 2 * kDuoBlock < n) gather(ta);         // block k+2
+            } else {
+                advance(ta, 0);                                // block k
+                if (i > 0) emit(tb, i - kDuoBlock);            // block k-1
+            }
+            __syncthreads();
+            if (helper) {
+                if (i + 2 * kDuoBlock < n) {
+                    hand_over(ta, 0);                          // block k+2
+                    gather(tb);                                // block k+3
+                }
+            } else {
+                advance(tb, 1);                                // block k+1
+                emit(ta, i);                                   // block k
+            }
+            __syncthreads();
+        }
+        if (!helper) emit(tb, n - kDuoBlock);
+    }
+}
+
 // ---- every voice, one lane per individual ------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(kSynthMaxThreads) void k_synth(const float *__restrict__ values,
@@ -399,8 +666,7 @@ __global__ __launch_bounds__(kSynthMaxThreads) void k_synth(const float *__restr
                     const float cur = t1[u] * mod + fc;
                     y[u] = tab_at(tab, pos2);
                     pos2 += c * cur;
-                    wrap_hi(pos2);
-                    wrap_lo(pos2);
+                    wrap_both(pos2);
                 }
                 if (i > 0) {
 #pragma unroll
@@ -443,8 +709,7 @@ __global__ __launch_bounds__(kSynthMaxThreads) void k_synth(const float *__restr
                         const float cur = t[u] * mm + off;
                         t[u] = tab_at(tab, pos[o]);
                         pos[o] += c * cur;
-                        wrap_hi(pos[o]);
-                        wrap_lo(pos[o]);
+                        wrap_both(pos[o]);
                     }
                 }
 #pragma unroll
@@ -479,8 +744,7 @@ __global__ __launch_bounds__(kSynthMaxThreads) void k_synth(const float *__restr
                         const float cur = t1[u] * mod[j] + fc[j];
                         tot[j][u] = tab_at(tab, pb[j]) * amp[j];
                         pb[j] += c * cur;
-                        wrap_hi(pb[j]);
-                        wrap_lo(pb[j]);
+                        wrap_both(pb[j]);
                     }
                 }
 #pragma unroll
@@ -1271,6 +1535,24 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         const char *e = getenv("SOTS_SYNTH_PAIR"); // 0: always the one-lane-per-individual kernel (A/B profiling)
         return e ? atoi(e) != 0 : true;
     }();
+    static const bool use_staged = [] {
+        const char *e = getenv("SOTS_SYNTH_STAGED"); // experiment: whole-line stores through LDS
+        return e ? atoi(e) != 0 : false;
+    }();
+    static const bool use_duo = [] {
+        const char *e = getenv("SOTS_SYNTH_DUO"); // experiment: modulator and carrier in separate wavefronts
+        return e ? atoi(e) != 0 : false;
+    }();
+    if (kind == SOTS_SYNTH_2OP && use_duo) {
+        uint32_t pairs = (share + kWave - 1) / kWave;
+        pairs = pairs < 1 ? 1 : pairs > (uint32_t)kDuoMaxPairs ? (uint32_t)kDuoMaxPairs : pairs;
+        k_synth_duo<<<grid_for(p, pairs * kWave, cus), pairs * 2 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
+        return hipGetLastError();
+    }
+    if (kind == SOTS_SYNTH_2OP && use_staged) {
+        k_synth_staged<<<grid_for(p, kStagedThreads, cus), kStagedThreads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
+        return hipGetLastError();
+    }
     if (kind == SOTS_SYNTH_2OP && use_pair && share <= (uint32_t)kPairIndividuals) {
         // small share: two lanes per individual double the wavefronts per SIMD
         uint32_t per_block = ((share + 31) / 32) * 32;
