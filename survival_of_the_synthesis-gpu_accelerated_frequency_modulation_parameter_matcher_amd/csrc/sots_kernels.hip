@@ -14,6 +14,7 @@
 //
 // Reference citations are file:line in the reference tree.
 #include "sots_kernels.h"
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -183,11 +184,6 @@ __device__ __forceinline__ float4 nt_load4(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 #define SOTS_ROW_LOAD(p) nt_load4(p)
-// Row stores of the synthesis kernels stay ordinary: each 128-byte line is assembled in L2 from
-// eight 16-byte stores; a non-temporal store sends every piece to memory (measured 791 us
-// instead of 91 us).
-__device__ __forceinline__ void row_store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
-
 // ------------------------------------------------------------------------------------
 // synthesisePopulation{,DoubleSeries,TripleParallel}, ocl_program.cl:280-443 /
 // Objective::synthesiseAudio*, Evolutionary_Strategy.hpp:368-495.
@@ -195,29 +191,35 @@ __device__ __forceinline__ void row_store4(float *p, float4 v) { *reinterpret_ca
 // The oscillator phases are fp32 running sums with a conditional wrap per sample, so a
 // voice is serial in the sample index and cannot be split over lanes without changing the
 // rounding (and with it table indices and spectra).  The 32768-entry wavetable (128 KiB)
-// lives in LDS, one workgroup per CU.  Two kernels:
-//   k_synth_pair   2-operator voice, TWO lanes per individual (modulator chain in lanes
-//                  0-31, carrier chain in lanes 32-63 of a wavefront, values handed over
-//                  with v_permlane32_swap).  At P = 65536 that puts two wavefronts on
-//                  every SIMD instead of one, so table-read latency and the row-per-lane
-//                  stores of one wavefront hide behind the other's arithmetic.
-//   k_synth        every voice, one lane per individual, phase chains of 8 samples run
-//                  ahead of the table reads that hang off them.
-// Both follow the per-sample operation order of the reference exactly.
+// lives in LDS, one workgroup per CU, which leaves 32 KiB of LDS.  Two kernels:
+//   k_synth      every voice, one lane per individual.  A voice is J parallel chains of OPS
+//                operators in series; operator s of block k-s runs in loop trip k (software
+//                pipeline over blocks of 8 samples, two alternating register sets, no copies),
+//                so no table read is waited for in the trip that issues it.  Finished samples
+//                are parked in a swizzled LDS tile and leave as whole 128-byte lines.
+//   k_synth_duo  2-operator voice for small populations (at most two wavefronts per CU):
+//                modulator and carrier recurrences in separate wavefronts.
+// With one wavefront per SIMD every vector instruction costs four cycles, whatever it does, so
+// the instruction count per sample is what the loop time follows (in-kernel s_memtime stamps,
+// -DSOTS_STAMP): branch-free wraps (below), packed v_pk_* arithmetic for the per-sample
+// mul/add/mul outside the recurrences.  Every per-sample operation is the reference's, in
+// its order, unfused, so the audio is bit-identical to the serial loop.
 // ------------------------------------------------------------------------------------
-constexpr int kSynthMaxThreads = 1024; // largest: four per SIMD
-constexpr int kSynthUnroll = 8;
+constexpr int kSynthUnroll = 8; // samples per pipeline block
 constexpr float kWf = (float)kWavetableSize;
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 
+// table[clamp((int)pos, 0, W-1)]; CLAMP = false only where the phase is known to be in [0, W)
+template <bool CLAMP = true>
 __device__ __forceinline__ float tab_at(const float *tab, float pos)
 {
-    int i = (int)pos; // == (unsigned)pos for every in-range phase
-    i = min(max(i, 0), (int)kWavetableSize - 1);
-#ifdef SOTS_ABLATE_GATHER
-    return __int_as_float(i); // timing experiment only: no LDS read
-#else
-    return tab[i];
-#endif
+    if constexpr (CLAMP) {
+        int i = (int)pos; // == (unsigned)pos for every in-range phase
+        i = min(max(i, 0), (int)kWavetableSize - 1);
+        return tab[i];
+    } else {
+        return tab[(uint32_t)pos];
+    }
 }
 // The reference's two conditional wraps, `if (p >= W) p -= W;` and `if (p < 0) p += W;`, as
 // subtract/add and an UNSIGNED INTEGER minimum of the bit patterns.  Non-negative floats order
@@ -239,147 +241,83 @@ __device__ __forceinline__ void wrap_hi(float &p)
 }
 __device__ __forceinline__ void wrap_both(float &p)
 {
-    p = __uint_as_float(min(min(__float_as_uint(p - kWf), __float_as_uint(p + kWf)), __float_as_uint(p)));
+    const v2f_t bc = v2f_t{p, p} + v2f_t{-kWf, kWf}; // one v_pk_add_f32
+    p = __uint_as_float(min(min(__float_as_uint(bc.x), __float_as_uint(bc.y)), __float_as_uint(p)));
 }
 
 __device__ __forceinline__ void load_wavetable(float *__restrict__ tab, const float *__restrict__ wavetable)
 {
-    for (uint32_t i = threadIdx.x * 4u; i < kWavetableSize; i += blockDim.x * 4u)
-        *reinterpret_cast<float4 *>(&tab[i]) = *reinterpret_cast<const float4 *>(&wavetable[i]);
+    // global -> LDS directly (global_load_lds_dwordx4): one wavefront instruction lands 1 KiB at a
+    // wavefront-uniform LDS base + lane * 16 B, no registers in between, all 128 in flight at once
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+    const uint32_t waves = blockDim.x / kWave;
+    constexpr uint32_t kChunk = kWave * 4; // floats per instruction
+    for (uint32_t ch = wave; ch < kWavetableSize / kChunk; ch += waves)
+        __builtin_amdgcn_global_load_lds(wavetable + ch * kChunk + lane * 4u, (lds_ptr_t)(tab + ch * kChunk), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the copies have landed
     __syncthreads();
 }
 
-__device__ __forceinline__ void store_block(float *__restrict__ out, const float (&y)[kSynthUnroll], uint32_t i,
-                                            bool active)
-{
-#ifdef SOTS_ABLATE_STORE
-    float acc = 0.f;
-#pragma unroll
-    for (int u = 0; u < kSynthUnroll; ++u) acc += y[u];
-    if (acc == 123.456f) out[i] = acc; // timing experiment only: keeps the work alive, never stores
-#else
-    if (active) {
-#pragma unroll
-        for (int u = 0; u < kSynthUnroll; u += 4)
-            row_store4(out + i + u, make_float4(y[u], y[u + 1], y[u + 2], y[u + 3]));
+#ifdef SOTS_STAMP
+// Diagnostic build only (never the shipped library): per-wavefront shader cycles and 100 MHz
+// ticks around the synthesis loop, read back with sots_debug_stamps().
+__device__ unsigned long long g_stamps[2 * 16384];
+struct StampScope {
+    unsigned long long t0, r0;
+    uint32_t slot;
+    __device__ StampScope(uint32_t s) : slot(s)
+    {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
     }
-#endif
-}
-
-// ---- 2-operator voice, lane pair per individual ---------------------------------------
-constexpr int kPairThreads = 512;                        // 8 wavefronts x 32 individuals
-constexpr int kPairIndividuals = kPairThreads / 2;
-
-// One step of both chains.  Lane roles differ only in two constants:
-//   carrier  lane: step = c * (x * mod + fc)   with x = the modulator lane's table value
-//   modulator lane: step = c * (x * 0   + P0)  = c * P0, the constant modulator increment
-// (x * 0 is +-0 for the finite table values x can take, so the sum is exactly P0).
-// `slot` holds the table value this lane requested kPairLag steps ago; it is consumed and
-// then refilled with a new request, so a table read has kPairLag steps to arrive.
-constexpr int kPairLag = 4;
-constexpr int kPairTrip = 32; // steps per loop trip (N is a multiple of it)
-
-__device__ __forceinline__ float pair_step(const float *tab, float &pos, float &slot, float mul_l, float add_l, float c)
-{
-    const float told = slot;
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(told), __float_as_uint(told), false, false);
-    const float x = __uint_as_float(sw[0]); // lanes 32-63: partner lane's value; lanes 0-31: own
-    slot = tab_at(tab, pos);
-    const float cur = x * mul_l + add_l;
-    pos += c * cur;
-    wrap_both(pos);
-    // keep this step's table request inside the step: left alone, the scheduler sinks the four
-    // requests of an unrolled iteration to its end and their latency is exposed again
-    __builtin_amdgcn_sched_barrier(0);
-    return told;
-}
-
-__global__ __launch_bounds__(kPairThreads) void k_synth_pair(const float *__restrict__ values,
-                                                             const float *__restrict__ wavetable,
-                                                             float *__restrict__ audio, SynthParams sp,
-                                                             uint32_t p_len, uint32_t n, uint32_t pitch)
-{
-    __shared__ float tab[kWavetableSize];
-    load_wavetable(tab, wavetable);
-    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const bool carrier = lane >= 32;
-
-    const uint32_t per_block = blockDim.x / 2; // individuals per workgroup
-    for (uint32_t base = blockIdx.x * per_block; base < p_len; base += gridDim.x * per_block) {
-        const uint32_t slot_id = base + wave * 32 + (lane & 31);
-        const bool active = slot_id < p_len; // all lanes keep running (the swap crosses lanes)
-        const uint32_t ind = active ? slot_id : p_len - 1u;
-        const float4 v = *reinterpret_cast<const float4 *>(values + (size_t)ind * 4);
-        // scaleParams: min + v*(max-min), ocl_program.cl:297
-        const float p0 = sp.pmin[0] + v.x * (sp.pmax[0] - sp.pmin[0]);
-        const float p1 = sp.pmin[1] + v.y * (sp.pmax[1] - sp.pmin[1]);
-        const float p2 = sp.pmin[2] + v.z * (sp.pmax[2] - sp.pmin[2]);
-        const float p3 = sp.pmin[3] + v.w * (sp.pmax[3] - sp.pmin[3]);
-        const float mod = p0 * p1, amp = p3; // Evolutionary_Strategy.hpp:372-376
-        const float mul_l = carrier ? mod : 0.0f;
-        const float add_l = carrier ? p2 : p0;
-        float *__restrict__ out = audio + (size_t)ind * pitch;
-
-        // The modulator chain runs kPairLag samples ahead of the carrier chain, and a carrier
-        // table value is turned into an output sample kPairLag steps after it was requested.
-        float pos = 0.0f;
-        float r[kPairLag];
-#pragma unroll
-        for (int u = 0; u < kPairLag; ++u) r[u] = 0.0f;
-        if (!carrier) {
-#pragma unroll
-            for (int u = 0; u < kPairLag; ++u) {
-                r[u] = tab_at(tab, pos);
-                pos += c * p0;
-                wrap_hi(pos);
-            }
-        }
-        // step j: carrier works on sample j, emits sample j - kPairLag.  Each trip of the outer
-        // loop is kPairTrip steps, fully unrolled: table requests stay in flight across the
-        // 4-step groups inside a trip and are only drained at the loop back-edge.
-        {
-            float y[kPairLag];
-#pragma unroll
-            for (int u = 0; u < kPairLag; ++u) y[u] = pair_step(tab, pos, r[u], mul_l, add_l, c) * amp; // samples < 0: dropped
-        }
-        for (uint32_t i = 0; i < n; i += kPairTrip) {
-#pragma unroll
-            for (int b = 0; b < kPairTrip; b += kPairLag) {
-                float y[kPairLag];
-#pragma unroll
-                for (int u = 0; u < kPairLag; ++u) y[u] = pair_step(tab, pos, r[u], mul_l, add_l, c) * amp;
-#ifdef SOTS_ABLATE_STORE
-                if (y[0] + y[1] + y[2] + y[3] == 123.456f) out[i] = y[0];
-#else
-                if (carrier && active) row_store4(out + i + b, make_float4(y[0], y[1], y[2], y[3]));
-#endif
-            }
+    __device__ ~StampScope()
+    {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0 && slot < 16384) {
+            g_stamps[2 * slot] = t1 - t0;
+            g_stamps[2 * slot + 1] = r1 - r0;
         }
     }
-}
+};
+#define SOTS_STAMP_SCOPE(slot) StampScope stamp_scope_(slot)
+#else
+#define SOTS_STAMP_SCOPE(slot)
+#endif
 
-// ---- 2-operator voice, one lane per individual, whole-line stores through LDS -------------
-// EXPERIMENT (SOTS_SYNTH_STAGED=1).  Four wavefronts, each with a private 8 KiB tile
-// [64 rows][8 chunks of 16 B], XOR-swizzled by row so that both the row-wise writes (lane =
-// row) and the transposed reads (lane = 8 rows x 8 chunks) are bank-conflict free.  Every 32
-// samples the tile is read back transposed and written with stores in which 8 neighbouring
-// lanes cover one whole 128-byte line of one row.
-constexpr int kStagedThreads = 256;
+// ---- every voice, one lane per individual, whole-line stores through LDS -------------------
+// Each wavefront owns an 8 KiB tile [64 rows][8 chunks of 16 B], XOR-swizzled by row so that
+// both the row-wise writes (lane = row) and the transposed reads (lane = 8 rows x 8 chunks) are
+// bank-conflict free.  Every 32 samples the tile is read back transposed and written with
+// stores in which 8 neighbouring lanes cover one whole 128-byte line of one row.  (The
+// row-per-lane 16-byte store it replaces touches 64 lines per instruction and 8 L2 requests
+// per line: 91 us instead of 57 us for the 2-operator voice at P = 65536.)
+constexpr int kSynthWaves = 4;  // at most: one per SIMD, 4 x 8 KiB of tiles beside the table
 constexpr int kStageChunks = 8; // 16-byte chunks per row per flush = 32 samples
 
-__global__ __launch_bounds__(kStagedThreads) void k_synth_staged(const float *__restrict__ values,
-                                                                 const float *__restrict__ wavetable,
-                                                                 float *__restrict__ audio, SynthParams sp,
-                                                                 uint32_t p_len, uint32_t n, uint32_t pitch)
+template <int KIND> struct VoiceShape;
+template <> struct VoiceShape<SOTS_SYNTH_2OP> { static constexpr int J = 1, OPS = 2, D = 4; };
+template <> struct VoiceShape<SOTS_SYNTH_3OP_SERIES> { static constexpr int J = 1, OPS = 3, D = 6; };
+template <> struct VoiceShape<SOTS_SYNTH_4OP_SERIES> { static constexpr int J = 1, OPS = 4, D = 8; };
+template <> struct VoiceShape<SOTS_SYNTH_TRIPLE_PAR> { static constexpr int J = 3, OPS = 2, D = 12; };
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+template <int KIND>
+__global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__restrict__ values,
+                                                               const float *__restrict__ wavetable,
+                                                               float *__restrict__ audio, SynthParams sp,
+                                                               uint32_t p_len, uint32_t n, uint32_t pitch)
 {
+    constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
+    constexpr int U = kSynthUnroll;
     __shared__ float tab[kWavetableSize];
-    __shared__ float4 stage_all[(kStagedThreads / kWave) * kWave * kStageChunks];
+    __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
     load_wavetable(tab, wavetable);
-    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
+    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
-    // write side: lane = row; chunk c of the row lives in slot c ^ (row & 7)
+    // write side: lane = row; chunk q of the row lives in slot q ^ (row & 7)
     float4 *__restrict__ wr = stage + lane * kStageChunks;
     const uint32_t l7 = lane & 7u;
     // read side: lane = (row & 7 within a group of 8 rows, chunk): group `it` adds 64 slots
@@ -387,91 +325,164 @@ __global__ __launch_bounds__(kStagedThreads) void k_synth_staged(const float *__
     const float4 *__restrict__ rd = stage + r8 * kStageChunks + (l7 ^ r8);
     const uint32_t lane_off = r8 * pitch + 4u * l7; // floats, relative to the group's first row
 
-    for (uint32_t base = blockIdx.x * kStagedThreads; base < p_len; base += gridDim.x * kStagedThreads) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < p_len; base += gridDim.x * blockDim.x) {
         const uint32_t row0 = base + wave * kWave; // first row of this wavefront
-        const bool active = row0 + lane < p_len;
-        const uint32_t ind = active ? row0 + lane : p_len - 1u;
-        const float4 v = *reinterpret_cast<const float4 *>(values + (size_t)ind * 4);
-        const float p0 = sp.pmin[0] + v.x * (sp.pmax[0] - sp.pmin[0]);
-        const float p1 = sp.pmin[1] + v.y * (sp.pmax[1] - sp.pmin[1]);
-        const float fc = sp.pmin[2] + v.z * (sp.pmax[2] - sp.pmin[2]);
-        const float amp = sp.pmin[3] + v.w * (sp.pmax[3] - sp.pmin[3]);
-        const float mod = p0 * p1, inc1 = c * p0;
+        const uint32_t ind = row0 + lane < p_len ? row0 + lane : p_len - 1u;
         const bool full = row0 + kWave <= p_len; // every row of the tile exists
-        float pos1 = 0.0f, pos2 = 0.0f;
-        // Two register sets (a, b) alternate so that no block is ever copied: while block k's
-        // carrier reads land in one set, block k-1's results leave from the other.
-        float ta[kSynthUnroll], tb[kSynthUnroll], ya[kSynthUnroll], yb[kSynthUnroll];
-        auto modulator = [&](float (&t)[kSynthUnroll]) { // stage A: table reads of the next block
+        float p[D];
 #pragma unroll
-            for (int u = 0; u < kSynthUnroll; ++u) {
-                t[u] = tab_at(tab, pos1);
-                pos1 += inc1;
-                wrap_hi(pos1);
-            }
-        };
-        auto carrier = [&](const float (&t)[kSynthUnroll], float (&y)[kSynthUnroll]) { // stage B
-#pragma unroll
-            for (int u = 0; u < kSynthUnroll; ++u) {
-                const float cur = t[u] * mod + fc;
-                y[u] = tab_at(tab, pos2);
-                pos2 += c * cur;
-                wrap_both(pos2);
-            }
-        };
-        auto emit = [&](const float (&y)[kSynthUnroll], uint32_t ip) { // stage C: samples ip..ip+7
-            const uint32_t c0 = (ip >> 2) & (kStageChunks - 1);
-            wr[c0 ^ l7] = make_float4(y[0] * amp, y[1] * amp, y[2] * amp, y[3] * amp);
-            wr[(c0 + 1) ^ l7] = make_float4(y[4] * amp, y[5] * amp, y[6] * amp, y[7] * amp);
-            if (c0 == kStageChunks - 2) { // 32 samples parked: flush the tile
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-                const uint32_t i0 = ip + kSynthUnroll - 4 * kStageChunks;
-                float *__restrict__ grp = audio + (size_t)row0 * pitch + i0 + lane_off;
-                if (full) {
-                    constexpr int G = 8 * kStageChunks; // slots per group of 8 rows
-                    const float4 q0 = rd[0 * G], q1 = rd[1 * G], q2 = rd[2 * G], q3 = rd[3 * G];
-                    const float4 q4 = rd[4 * G], q5 = rd[5 * G], q6 = rd[6 * G], q7 = rd[7 * G];
-                    const size_t g8 = (size_t)8u * pitch;
-                    *reinterpret_cast<float4 *>(grp + 0 * g8) = q0;
-                    *reinterpret_cast<float4 *>(grp + 1 * g8) = q1;
-                    *reinterpret_cast<float4 *>(grp + 2 * g8) = q2;
-                    *reinterpret_cast<float4 *>(grp + 3 * g8) = q3;
-                    *reinterpret_cast<float4 *>(grp + 4 * g8) = q4;
-                    *reinterpret_cast<float4 *>(grp + 5 * g8) = q5;
-                    *reinterpret_cast<float4 *>(grp + 6 * g8) = q6;
-                    *reinterpret_cast<float4 *>(grp + 7 * g8) = q7;
-                } else { // last, partly filled tile of the population
-#pragma unroll 1
-                    for (uint32_t it = 0; it < kWave / 8; ++it)
-                        if (row0 + 8u * it + r8 < p_len)
-                            *reinterpret_cast<float4 *>(grp + (size_t)(8u * it) * pitch) = rd[it * 8 * kStageChunks];
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-            }
-        };
-        modulator(ta);
-        for (uint32_t i = 0; i < n; i += 2 * kSynthUnroll) { // n is a multiple of 16 (n >= 512)
-            modulator(tb);
-            carrier(ta, ya);
-            if (i > 0) emit(yb, i - kSynthUnroll);
-            if (i + 2 * kSynthUnroll < n) modulator(ta);
-            carrier(tb, yb);
-            emit(ya, i);
+        for (int g = 0; g < D; ++g) {
+            // scaleParams: min + v*(max-min), ocl_program.cl:297; the triple voice scales all
+            // three 2-op voices by entries 0..3, Evolutionary_Strategy.hpp:453-455
+            const int sc = KIND == SOTS_SYNTH_TRIPLE_PAR ? (g & 3) : g;
+            p[g] = sp.pmin[sc] + values[(size_t)ind * D + g] * (sp.pmax[sc] - sp.pmin[sc]);
         }
-        emit(yb, n - kSynthUnroll);
+        // Operator 0 of chain j runs free at inc0[j]; operator s >= 1 advances by
+        // c * (t_prev * mul[s][j] + off[s][j]); the output is gain[j] * (last operator's table value).
+        float inc0[J], mul[OPS][J], off[OPS][J], gain[J];
+        if constexpr (KIND == SOTS_SYNTH_2OP) { // Evolutionary_Strategy.hpp:372-401
+            inc0[0] = c * p[0], mul[1][0] = p[0] * p[1], off[1][0] = p[2], gain[0] = p[3];
+        } else if constexpr (KIND == SOTS_SYNTH_TRIPLE_PAR) { // :457-494
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                inc0[j] = c * p[4 * j], mul[1][j] = p[4 * j] * p[4 * j + 1], off[1][j] = p[4 * j + 2], gain[j] = p[4 * j + 3];
+        } else { // series, :407-445 (the 4-operator voice adds one more modulator stage)
+            inc0[0] = c * p[1];
+#pragma unroll
+            for (int o = 1; o < OPS; ++o) mul[o][0] = p[2 * (o - 1)] * p[2 * (o - 1) + 1], off[o][0] = p[2 * (o - 1) + 3];
+            gain[0] = p[2 * (OPS - 1)] * p[2 * (OPS - 1) + 1];
+        }
+        // a free-running phase stays inside [0, W) when 0 <= inc0 < W: its index needs no clamp
+        bool in_range = true;
+#pragma unroll
+        for (int j = 0; j < J; ++j) in_range = in_range && inc0[j] >= 0.0f && inc0[j] < kWf;
+        const bool free_unclamped = __all(in_range);
+        SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave);
+
+        auto run = [&](auto unclamped_tag) {
+            constexpr bool UNCLAMPED = decltype(unclamped_tag)::value;
+            float pos[OPS][J];
+#pragma unroll
+            for (int o = 0; o < OPS; ++o)
+#pragma unroll
+                for (int j = 0; j < J; ++j) pos[o][j] = 0.0f;
+            float T[OPS][2][J][U]; // table values of operator s, block parity, chain, sample
+
+            // operator S on the block of parity Q
+            auto op = [&](auto s_tag, auto q_tag) {
+                constexpr int S = decltype(s_tag)::value, Q = decltype(q_tag)::value;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    if constexpr (S == 0) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            T[0][Q][j][u] = tab_at<!UNCLAMPED>(tab, pos[0][j]);
+                            pos[0][j] += inc0[j];
+                            wrap_hi(pos[0][j]);
+                        }
+                    } else {
+                        // phase increments, two samples per packed instruction (v_pk_mul_f32,
+                        // v_pk_add_f32, v_pk_mul_f32: the reference's mul, add, mul, unfused)
+                        v2f_t inc[U / 2];
+#pragma unroll
+                        for (int u = 0; u < U; u += 2)
+                            inc[u / 2] = (v2f_t{T[S - 1][Q][j][u], T[S - 1][Q][j][u + 1]} * mul[S][j] + off[S][j]) * c;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            T[S][Q][j][u] = tab_at(tab, pos[S][j]);
+                            pos[S][j] += (u & 1) ? inc[u / 2].y : inc[u / 2].x;
+                            wrap_both(pos[S][j]);
+                        }
+                    }
+                }
+            };
+            // samples ip..ip+7 (the block of parity Q) leave
+            auto emit = [&](auto q_tag, uint32_t ip) {
+                constexpr int Q = decltype(q_tag)::value;
+                float y[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if constexpr (KIND == SOTS_SYNTH_TRIPLE_PAR)
+                        y[u] = (T[OPS - 1][Q][0][u] * gain[0] + T[OPS - 1][Q][1][u] * gain[1] + T[OPS - 1][Q][2][u] * gain[2]) /
+                               3.0f; // == (float)(double(sum)/3.0), :493
+                    else
+                        y[u] = T[OPS - 1][Q][0][u] * gain[0];
+                }
+                const uint32_t c0 = (ip >> 2) & (kStageChunks - 1);
+                wr[c0 ^ l7] = make_float4(y[0], y[1], y[2], y[3]);
+                wr[(c0 + 1) ^ l7] = make_float4(y[4], y[5], y[6], y[7]);
+                if (c0 == kStageChunks - 2) { // 32 samples parked: flush the tile
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                    const uint32_t i0 = ip + U - 4 * kStageChunks;
+                    float *__restrict__ grp = audio + (size_t)row0 * pitch + i0 + lane_off;
+                    if (full) {
+                        constexpr int G = 8 * kStageChunks; // slots per group of 8 rows
+                        const float4 q0 = rd[0 * G], q1 = rd[1 * G], q2 = rd[2 * G], q3 = rd[3 * G];
+                        const float4 q4 = rd[4 * G], q5 = rd[5 * G], q6 = rd[6 * G], q7 = rd[7 * G];
+                        const size_t g8 = (size_t)8u * pitch;
+                        *reinterpret_cast<float4 *>(grp + 0 * g8) = q0;
+                        *reinterpret_cast<float4 *>(grp + 1 * g8) = q1;
+                        *reinterpret_cast<float4 *>(grp + 2 * g8) = q2;
+                        *reinterpret_cast<float4 *>(grp + 3 * g8) = q3;
+                        *reinterpret_cast<float4 *>(grp + 4 * g8) = q4;
+                        *reinterpret_cast<float4 *>(grp + 5 * g8) = q5;
+                        *reinterpret_cast<float4 *>(grp + 6 * g8) = q6;
+                        *reinterpret_cast<float4 *>(grp + 7 * g8) = q7;
+                    } else { // last, partly filled tile of the population
+#pragma unroll 1
+                        for (uint32_t it = 0; it < kWave / 8; ++it)
+                            if (row0 + 8u * it + r8 < p_len)
+                                *reinterpret_cast<float4 *>(grp + (size_t)(8u * it) * pitch) = rd[it * 8 * kStageChunks];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            };
+            // Trip k of parity Q: operator s works on block k - s (parity Q ^ (s & 1)) for
+            // s in [SMIN, min(SMAX, OPS-1)], and block k - OPS leaves when SMAX == OPS.
+            auto trip = [&](auto q_tag, auto smin_tag, auto smax_tag, uint32_t k) {
+                constexpr int Q = decltype(q_tag)::value, SMIN = decltype(smin_tag)::value, SMAX = decltype(smax_tag)::value;
+                if constexpr (SMIN <= 0 && 0 <= SMAX) op(ic<0>{}, ic<Q>{});
+                if constexpr (SMIN <= 1 && 1 <= SMAX && 1 < OPS) op(ic<1>{}, ic<Q ^ 1>{});
+                if constexpr (SMIN <= 2 && 2 <= SMAX && 2 < OPS) op(ic<2>{}, ic<Q>{});
+                if constexpr (SMIN <= 3 && 3 <= SMAX && 3 < OPS) op(ic<3>{}, ic<Q ^ 1>{});
+                if constexpr (SMAX == OPS) emit(ic<Q ^ (OPS & 1)>{}, (k - OPS) * U);
+            };
+            const uint32_t nb = n / U; // even and >= 64
+            constexpr int K0 = (OPS + 1) & ~1; // first trip with every stage busy, rounded to even
+            // fill: trip k runs operators 0..min(k, OPS) - the stage index OPS is the emit
+            trip(ic<0>{}, ic<0>{}, ic<0>{}, 0);
+            trip(ic<1>{}, ic<0>{}, ic<1>{}, 1);
+            if constexpr (K0 > 2) {
+                trip(ic<0>{}, ic<0>{}, ic<2>{}, 2);
+                trip(ic<1>{}, ic<0>{}, ic<(OPS < 3 ? OPS : 3)>{}, 3);
+            }
+            for (uint32_t k = K0; k < nb; k += 2) {
+                trip(ic<0>{}, ic<0>{}, ic<OPS>{}, k);
+                trip(ic<1>{}, ic<0>{}, ic<OPS>{}, k + 1);
+            }
+            // drain: trip nb + j runs stages j+1..OPS
+            trip(ic<0>{}, ic<1>{}, ic<OPS>{}, nb);
+            trip(ic<1>{}, ic<2>{}, ic<OPS>{}, nb + 1);
+            if constexpr (OPS > 2) trip(ic<0>{}, ic<3>{}, ic<OPS>{}, nb + 2);
+            if constexpr (OPS > 3) trip(ic<1>{}, ic<4>{}, ic<OPS>{}, nb + 3);
+        };
+        if (free_unclamped) run(std::true_type{});
+        else run(std::false_type{});
     }
 }
 
 // ---- 2-operator voice, a modulator wavefront and a carrier wavefront per 64 individuals ------
-// EXPERIMENT (SOTS_SYNTH_DUO=1).  The modulator phase never depends on the carrier, so the
-// two recurrences run in different wavefronts: the HELPER advances the modulator phase, reads
+// The modulator phase never depends on the carrier, so the two recurrences run in different
+// wavefronts: the HELPER advances the modulator phase, reads
 // the table and hands c * (t * mod + fc) - the carrier's phase increment - over through LDS,
 // eight samples at a time; the CARRIER advances its phase, reads the table, scales and parks
 // the samples in a swizzled [64 rows][16 samples] tile that it flushes with stores in which four
 // neighbouring lanes cover 64 contiguous bytes of one row.  Each per-sample operation is the
-// reference's, in its order, so the result is bit-identical to k_synth<2OP>.
+// reference's, in its order, so the result is bit-identical to k_synth<2OP>.  Used when a CU's share is at most 128
+// individuals: each wavefront then carries half the instructions (in-kernel 80 instead of 100
+// cycles per sample); with four pairs per CU the barrier every 8 samples costs more than that.
 constexpr int kDuoMaxPairs = 4;                // carrier/helper pairs per workgroup
 constexpr int kDuoBlock = 8;                   // samples per hand-over
 constexpr int kDuoTileChunks = 4;              // 16-byte chunks per staged row (16 samples)
@@ -511,6 +522,7 @@ __global__ __launch_bounds__(kDuoMaxPairs * 2 * kWave) void k_synth_duo(const fl
         const float amp = sp.pmin[3] + v.w * (sp.pmax[3] - sp.pmin[3]);
         const float mod = p0 * p1, inc1 = c * p0;
         const bool full = row0 + kWave <= p_len;
+        SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave);
         float pos = 0.0f; // the helper's modulator phase or the carrier's phase
         float ta[kDuoBlock], tb[kDuoBlock];
 
@@ -525,12 +537,9 @@ __global__ __launch_bounds__(kDuoMaxPairs * 2 * kWave) void k_synth_duo(const fl
         auto hand_over = [&](const float (&t)[kDuoBlock], uint32_t buf) { // helper: increments of one block
 #pragma unroll
             for (int j = 0; j < kDuoBlock / 4; ++j) {
-                float4 q;
-                q.x = c * (t[4 * j + 0] * mod + fc);
-                q.y = c * (t[4 * j + 1] * mod + fc);
-                q.z = c * (t[4 * j + 2] * mod + fc);
-                q.w = c * (t[4 * j + 3] * mod + fc);
-                xinc[buf][j][lane] = q;
+                const v2f_t lo = (v2f_t{t[4 * j + 0], t[4 * j + 1]} * mod + fc) * c; // packed mul, add, mul
+                const v2f_t hi = (v2f_t{t[4 * j + 2], t[4 * j + 3]} * mod + fc) * c;
+                xinc[buf][j][lane] = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         };
         auto advance = [&](float (&y)[kDuoBlock], uint32_t buf) { // carrier: one block of the recurrence
@@ -604,155 +613,6 @@ __global__ __launch_bounds__(kDuoMaxPairs * 2 * kWave) void k_synth_duo(const fl
             __syncthreads();
         }
         if (!helper) emit(tb, n - kDuoBlock);
-    }
-}
-
-// ---- every voice, one lane per individual ------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(kSynthMaxThreads) void k_synth(const float *__restrict__ values,
-                                                         const float *__restrict__ wavetable,
-                                                         float *__restrict__ audio, SynthParams sp,
-                                                         uint32_t p_len, uint32_t n, uint32_t pitch)
-{
-    __shared__ float tab[kWavetableSize];
-    load_wavetable(tab, wavetable);
-
-    constexpr int D = KIND == SOTS_SYNTH_2OP ? 4 : KIND == SOTS_SYNTH_3OP_SERIES ? 6
-                    : KIND == SOTS_SYNTH_TRIPLE_PAR ? 12 : 8;
-    // w2srRatio, Evolutionary_Strategy.hpp:203
-    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
-
-    for (uint32_t base = blockIdx.x * blockDim.x; base < p_len; base += gridDim.x * blockDim.x) {
-        const bool active = base + threadIdx.x < p_len;
-        const uint32_t ind = active ? base + threadIdx.x : p_len - 1u;
-        float p[D];
-#pragma unroll
-        for (int g = 0; g < D; ++g) {
-            // scaleParams: min + v*(max-min), ocl_program.cl:297; the triple voice scales all
-            // three 2-op voices by entries 0..3, Evolutionary_Strategy.hpp:453-455
-            const int s = KIND == SOTS_SYNTH_TRIPLE_PAR ? (g & 3) : g;
-            p[g] = sp.pmin[s] + values[(size_t)ind * D + g] * (sp.pmax[s] - sp.pmin[s]);
-        }
-        float *__restrict__ out = audio + (size_t)ind * pitch;
-
-        if constexpr (KIND == SOTS_SYNTH_2OP) {
-            // Evolutionary_Strategy.hpp:372-401, as a three-stage software pipeline over blocks of
-            // 8 samples so that no table read is waited for in the phase that issues it:
-            //   stage A (block b+1): modulator phase chain, issues its 8 table reads
-            //   stage B (block b)  : carrier phase chain from A's values, issues the 8 output reads
-            //   stage C (block b-1): amplitude, 16-byte stores
-            // Same arithmetic in the same per-sample order as the serial loop.
-            const float mod = p[0] * p[1], fc = p[2], amp = p[3];
-            const float inc1 = c * p[0];
-            float pos1 = 0.0f, pos2 = 0.0f;
-            float t1[kSynthUnroll], t1n[kSynthUnroll], y[kSynthUnroll], yp[kSynthUnroll];
-#pragma unroll
-            for (int u = 0; u < kSynthUnroll; ++u) {
-                t1[u] = tab_at(tab, pos1);
-                pos1 += inc1;
-                wrap_hi(pos1);
-            }
-            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
-                if (i + kSynthUnroll < n) {
-#pragma unroll
-                    for (int u = 0; u < kSynthUnroll; ++u) {
-                        t1n[u] = tab_at(tab, pos1);
-                        pos1 += inc1;
-                        wrap_hi(pos1);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u) {
-                    const float cur = t1[u] * mod + fc;
-                    y[u] = tab_at(tab, pos2);
-                    pos2 += c * cur;
-                    wrap_both(pos2);
-                }
-                if (i > 0) {
-#pragma unroll
-                    for (int u = 0; u < kSynthUnroll; ++u) yp[u] = yp[u] * amp;
-                    store_block(out, yp, i - kSynthUnroll, active);
-                }
-#pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u) {
-                    t1[u] = t1n[u];
-                    yp[u] = y[u];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kSynthUnroll; ++u) yp[u] = yp[u] * amp;
-            store_block(out, yp, n - kSynthUnroll, active);
-        } else if constexpr (KIND == SOTS_SYNTH_3OP_SERIES || KIND == SOTS_SYNTH_4OP_SERIES) {
-            // Evolutionary_Strategy.hpp:407-445; the 4-op voice adds one more modulator stage
-            constexpr int OPS = KIND == SOTS_SYNTH_3OP_SERIES ? 3 : 4;
-            float m[OPS];
-#pragma unroll
-            for (int o = 0; o < OPS; ++o) m[o] = p[2 * o] * p[2 * o + 1];
-            const float inc1 = c * p[1];
-            float pos[OPS];
-#pragma unroll
-            for (int o = 0; o < OPS; ++o) pos[o] = 0.0f;
-            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
-                float t[kSynthUnroll], y[kSynthUnroll];
-#pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u) {
-                    t[u] = tab_at(tab, pos[0]);
-                    pos[0] += inc1;
-                    wrap_hi(pos[0]);
-                }
-#pragma unroll
-                for (int o = 1; o < OPS; ++o) {
-                    // offset of modulator o-1 is params[2(o-1)+3] (:420,427)
-                    const float mm = m[o - 1], off = p[2 * (o - 1) + 3];
-#pragma unroll
-                    for (int u = 0; u < kSynthUnroll; ++u) {
-                        const float cur = t[u] * mm + off;
-                        t[u] = tab_at(tab, pos[o]);
-                        pos[o] += c * cur;
-                        wrap_both(pos[o]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u) y[u] = t[u] * m[OPS - 1];
-                store_block(out, y, i, active);
-            }
-        } else {
-            // Evolutionary_Strategy.hpp:457-494
-            float mod[3], fc[3], amp[3], inc[3], pa[3], pb[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                mod[j] = p[4 * j] * p[4 * j + 1];
-                fc[j] = p[4 * j + 2];
-                amp[j] = p[4 * j + 3];
-                inc[j] = c * p[4 * j];
-                pa[j] = 0.0f;
-                pb[j] = 0.0f;
-            }
-            for (uint32_t i = 0; i < n; i += kSynthUnroll) {
-                float tot[3][kSynthUnroll], y[kSynthUnroll];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float t1[kSynthUnroll];
-#pragma unroll
-                    for (int u = 0; u < kSynthUnroll; ++u) {
-                        t1[u] = tab_at(tab, pa[j]);
-                        pa[j] += inc[j];
-                        wrap_hi(pa[j]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < kSynthUnroll; ++u) {
-                        const float cur = t1[u] * mod[j] + fc[j];
-                        tot[j][u] = tab_at(tab, pb[j]) * amp[j];
-                        pb[j] += c * cur;
-                        wrap_both(pb[j]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kSynthUnroll; ++u)
-                    y[u] = (tot[0][u] + tot[1][u] + tot[2][u]) / 3.0f; // == (float)(double(sum)/3.0), :493
-                store_block(out, y, i, active);
-            }
-        }
     }
 }
 
@@ -1529,40 +1389,20 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     const uint32_t n = 1u << log2n;
     const uint32_t cus = num_cus ? num_cus : 256;
     // The 128 KiB table allows one workgroup per CU, so the workgroup is sized to the CU's share
-    // of the population: more wavefronts per SIMD hide more of the table-read and store latency.
+    // of the population, up to one wavefront per SIMD; larger populations loop.
     const uint32_t share = (p + cus - 1) / cus;
-    static const bool use_pair = [] {
-        const char *e = getenv("SOTS_SYNTH_PAIR"); // 0: always the one-lane-per-individual kernel (A/B profiling)
+    uint32_t waves = (share + kWave - 1) / kWave;
+    static const bool use_duo = [] {
+        const char *e = getenv("SOTS_SYNTH_DUO"); // 0: never the two-wavefront kernel (A/B profiling)
         return e ? atoi(e) != 0 : true;
     }();
-    static const bool use_staged = [] {
-        const char *e = getenv("SOTS_SYNTH_STAGED"); // experiment: whole-line stores through LDS
-        return e ? atoi(e) != 0 : false;
-    }();
-    static const bool use_duo = [] {
-        const char *e = getenv("SOTS_SYNTH_DUO"); // experiment: modulator and carrier in separate wavefronts
-        return e ? atoi(e) != 0 : false;
-    }();
-    if (kind == SOTS_SYNTH_2OP && use_duo) {
-        uint32_t pairs = (share + kWave - 1) / kWave;
-        pairs = pairs < 1 ? 1 : pairs > (uint32_t)kDuoMaxPairs ? (uint32_t)kDuoMaxPairs : pairs;
+    if (kind == SOTS_SYNTH_2OP && use_duo && waves <= 2) {
+        const uint32_t pairs = waves < 1 ? 1 : waves;
         k_synth_duo<<<grid_for(p, pairs * kWave, cus), pairs * 2 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
         return hipGetLastError();
     }
-    if (kind == SOTS_SYNTH_2OP && use_staged) {
-        k_synth_staged<<<grid_for(p, kStagedThreads, cus), kStagedThreads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
-        return hipGetLastError();
-    }
-    if (kind == SOTS_SYNTH_2OP && use_pair && share <= (uint32_t)kPairIndividuals) {
-        // small share: two lanes per individual double the wavefronts per SIMD
-        uint32_t per_block = ((share + 31) / 32) * 32;
-        per_block = per_block < 32 ? 32 : per_block;
-        k_synth_pair<<<grid_for(p, per_block, cus), 2 * per_block, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
-        return hipGetLastError();
-    }
-    uint32_t threads = ((share + kWave - 1) / kWave) * kWave;
-    threads = threads < (uint32_t)kWave ? (uint32_t)kWave : threads > (uint32_t)kSynthMaxThreads ? (uint32_t)kSynthMaxThreads : threads;
-    const uint32_t grid = grid_for(p, threads, cus);
+    waves = waves < 1 ? 1 : waves > (uint32_t)kSynthWaves ? (uint32_t)kSynthWaves : waves;
+    const uint32_t threads = waves * kWave, grid = grid_for(p, threads, cus);
     switch (kind) {
     case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
     case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
@@ -1731,3 +1571,17 @@ hipError_t launch_unpack_rows(hipStream_t st, float *values, float *steps, float
 }
 
 } // namespace sots
+
+#ifdef SOTS_STAMP
+extern "C" int sots_debug_stamps(unsigned long long *host, size_t n)
+{
+    if (n > 2 * 16384) n = 2 * 16384;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sots::g_stamps), n * sizeof(unsigned long long));
+}
+extern "C" int sots_debug_clear_stamps()
+{
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(sots::g_stamps)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 2 * 16384);
+}
+#endif
