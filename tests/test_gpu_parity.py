@@ -29,8 +29,9 @@ def fit_atol(O, tgt_audio):
     return FIT_ATOL_REL * float(np.sum(m * m)) + 1e-12
 
 
-def make_pair(pkg, O, parents, offspring, kind=0, log2n=10, block=32, gid_base=0, seed=SEED, pmin=None):
-    kw = dict(synth_kind=kind, audio_log2=log2n, param_min=pmin, param_max=PMAX[kind], seed=seed, gid_base=gid_base)
+def make_pair(pkg, O, parents, offspring, kind=0, log2n=10, block=32, gid_base=0, seed=SEED, pmin=None, pmax=None):
+    kw = dict(synth_kind=kind, audio_log2=log2n, param_min=pmin, param_max=pmax if pmax is not None else PMAX[kind],
+              seed=seed, gid_base=gid_base)
     es = pkg.HipES(parents, offspring, workgroup_size=block, **kw)
     ref = O.OracleES(parents, offspring, recomb_block=block, **kw)
     return es, ref
@@ -119,8 +120,9 @@ def test_synthesise_bitexact(pkg, O, kind, log2n):
 
 
 def test_synthesise_two_op_large_population_uses_lane_per_individual_kernel(pkg, O):
-    """Above 256 individuals per CU the 2-op voice runs k_synth (software-pipelined, one lane per
-    individual) instead of the lane-pair kernel; rows are spot-checked against the oracle."""
+    """Above 128 individuals per CU the 2-op voice runs k_synth (one lane per individual, four
+    wavefronts per workgroup, looping over tiles) instead of the two-wavefront kernel; rows are
+    spot-checked against the oracle."""
     parents, offspring = 16640, 49920          # P = 66560 = 260 per CU on 256 CUs
     es, _ = make_pair(pkg, O, parents, offspring, 0, 10)
     es.init_population(0)
@@ -142,6 +144,58 @@ def test_synthesise_nonzero_param_min(pkg, O):
     es.synthesise()
     ref.evaluate()
     assert np.array_equal(es.read_audio(), ref.audio())
+    es.close()
+
+
+# Parameter boxes far outside the reference's: negative and > Nyquist frequencies, so that phase
+# increments are negative or exceed the table length, phases leave [0, W) for good, the index
+# clamp acts on both sides and the free-running operators cannot take the clamp-free path.
+WILD = {0: ([-2000.0, -4.0, -30000.0, -1.0], [60000.0, 12.0, 90000.0, 2.0]),
+        1: ([-2000.0, -50000.0, -3.0, -20000.0, -4.0, -20000.0], [9000.0, 70000.0, 9.0, 40000.0, 6.0, 30000.0]),
+        2: ([-2000.0, -4.0, -30000.0, -1.0], [60000.0, 12.0, 90000.0, 2.0]),
+        3: ([-2000.0, -50000.0, -3.0, -20000.0, -4.0, -20000.0, -2.0, -9000.0],
+            [9000.0, 70000.0, 9.0, 40000.0, 6.0, 30000.0, 5.0, 20000.0])}
+
+
+@pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (0, 9, 30, 35), (1, 10, 64, 64),
+                                                          (2, 9, 64, 192), (3, 11, 32, 96)])
+def test_synthesise_wild_parameter_ranges_bitexact(pkg, O, kind, log2n, parents, offspring):
+    """The branch-free phase wraps (unsigned-minimum forms) and the index clamp must equal the
+    oracle's conditional wraps for every phase value, not only for in-range ones."""
+    pmin, pmax = WILD[kind]
+    es, ref = make_pair(pkg, O, parents, offspring, kind, log2n, block=1 if (parents + offspring) % 32 else 32,
+                        pmin=pmin, pmax=pmax)
+    es.init_population(0)
+    ref.init_population(0)
+    v, s, _ = es.read_population()
+    v[0] = 0.0
+    v[1] = 1.0
+    es.write_population(v, s, None)
+    ref.write_population(v, s, None)
+    es.synthesise()
+    ref.evaluate()
+    a, r = es.read_audio(), ref.audio()
+    assert np.isfinite(r).all()
+    assert np.array_equal(a, r)
+    es.close()
+
+
+def test_synthesise_wild_parameter_ranges_large_population(pkg, O):
+    """Same, on the lane-per-individual kernel (P above 128 per CU), where wavefronts whose
+    modulators all stay in range take the clamp-free index path and the others do not."""
+    pmin, pmax = [-300.0, 0.0, -30000.0, -1.0], [45000.0, 12.0, 90000.0, 2.0]
+    es, _ = make_pair(pkg, O, 16640, 49920, 0, 9, pmin=pmin, pmax=pmax)
+    es.init_population(0)
+    v, s, _ = es.read_population()
+    v[:64, 0] = np.linspace(0.01, 0.9, 64, dtype=np.float32)    # first wavefront: every modulator in range
+    v[64:128, 0] = 0.0                                           # second: negative increments
+    es.write_population(v, s, None)
+    es.synthesise()
+    audio = es.read_audio()
+    rng = np.random.default_rng(23)
+    rows = np.concatenate([np.arange(0, 130), rng.choice(es.P, 150, replace=False), [es.P - 1]])
+    for r in rows:
+        assert np.array_equal(audio[r], O.synth(0, v[r], pmin, pmax, es.N)), f"row {r}"
     es.close()
 
 
