@@ -1209,48 +1209,53 @@ constexpr int kRankThreads = 256;
 constexpr uint32_t kRankGroup = 8;      // tiles staged in LDS per workgroup (tile = 1024: 64 KiB)
 constexpr uint32_t kRankLdsKeys = 8192; // LDS capacity in keys
 
-// Workgroup (a, g): keys of tile a against tiles [g*group, (g+1)*group); writes one partial
-// count per key of a.  Against its own tile a key's count is its sorted index.
+// Workgroup (a, g): keys of tile a against tiles [g*GROUP, (g+1)*GROUP); writes one partial
+// count per key of a.  Keys are unique, so against its own tile a key's lower bound is its
+// sorted index and no tile needs a special case.  The tiles are staged by LDS-DMA (all pieces
+// in flight at once) and the GROUP x 4 binary searches of a thread advance together, one level
+// per trip, so a trip has GROUP x 4 independent LDS reads in flight instead of 4.
+template <uint32_t GROUP>
 __global__ __launch_bounds__(kRankThreads) void k_sort_rank_pairs(const uint64_t *__restrict__ keys,
                                                                   uint16_t *__restrict__ partial,
-                                                                  uint32_t n_pad, uint32_t tile, uint32_t group)
+                                                                  uint32_t n_pad, uint32_t tile)
 {
     __shared__ uint64_t s[kRankLdsKeys];
     const uint32_t a = blockIdx.x, g = blockIdx.y;
-    const uint32_t b0 = g * group;
-    const uint64_t *__restrict__ kb = keys + (size_t)b0 * tile;
-    for (uint32_t i = threadIdx.x; i < group * tile; i += kRankThreads) s[i] = kb[i];
+    const uint64_t *__restrict__ kb = keys + (size_t)g * GROUP * tile;
+    {
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
+        constexpr uint32_t kChunk = kWave * 2; // keys per wavefront instruction (16 B per lane)
+        for (uint32_t ch = wave; ch < GROUP * tile / kChunk; ch += kRankThreads / kWave)
+            __builtin_amdgcn_global_load_lds(kb + ch * kChunk + lane * 2u, (lds_ptr_t)(s + ch * kChunk), 16, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0); // the copies have landed
+    }
     __syncthreads();
     const uint64_t *__restrict__ ka = keys + (size_t)a * tile;
     uint16_t *__restrict__ out = partial + (size_t)g * n_pad + (size_t)a * tile;
     for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 4 * kRankThreads) {
         uint64_t x[4];
-        uint32_t total[4];
+        uint32_t pos[GROUP][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t i = i0 + q * kRankThreads;
             x[q] = i < tile ? ka[i] : 0ull;
-            total[q] = 0;
+#pragma unroll
+            for (uint32_t bb = 0; bb < GROUP; ++bb) pos[bb][q] = 0;
         }
-        for (uint32_t bb = 0; bb < group; ++bb) {
-            const uint64_t *__restrict__ sb = s + bb * tile;
-            if (b0 + bb == a) {
+        for (uint32_t step = tile >> 1; step >= 1; step >>= 1) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) total[q] += i0 + q * kRankThreads;
-                continue;
-            }
-            uint32_t pos[4] = {0, 0, 0, 0};
-            for (uint32_t step = tile >> 1; step >= 1; step >>= 1) {
+            for (uint32_t bb = 0; bb < GROUP; ++bb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pos[q] += (sb[pos[q] + step - 1] < x[q]) ? step : 0u;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) total[q] += pos[q] + ((sb[pos[q]] < x[q]) ? 1u : 0u);
+                for (int q = 0; q < 4; ++q) pos[bb][q] += (s[bb * tile + pos[bb][q] + step - 1] < x[q]) ? step : 0u;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t bb = 0; bb < GROUP; ++bb) total += pos[bb][q] + ((s[bb * tile + pos[bb][q]] < x[q]) ? 1u : 0u);
             const uint32_t i = i0 + q * kRankThreads;
-            if (i < tile) out[i] = (uint16_t)total[q];
+            if (i < tile) out[i] = (uint16_t)total;
         }
     }
 }
@@ -1535,7 +1540,12 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
     if (rank_merge) {
         uint16_t *partial = static_cast<uint16_t *>(scratch);
         const uint32_t group = rank_group(tile, tiles), groups = tiles / group;
-        k_sort_rank_pairs<<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile, group);
+        switch (group) {
+        case 8: k_sort_rank_pairs<8><<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile); break;
+        case 4: k_sort_rank_pairs<4><<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile); break;
+        case 2: k_sort_rank_pairs<2><<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile); break;
+        default: k_sort_rank_pairs<1><<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile); break;
+        }
         k_sort_rank_scatter<<<n_pad / 64, kRankThreads, 0, st>>>(keys, partial, vin, sin, fin, vout, sout, fout,
                                                                n_pad, groups, p, d);
         return hipGetLastError();
