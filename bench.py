@@ -175,6 +175,13 @@ def main():
             kernels[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt), "alg_bytes_per_candidate": alg_bytes}
     fitness = es.read_fitness()
     best = float(fitness[0])
+    # What crossing the boundary with HOST buffers would cost (never part of `value`): a blocking
+    # read of the whole population (values, steps, fitness) through the C-ABI, as a caller would do
+    # that inspects every generation; the product path itself keeps the population in HBM.
+    t_rb = time.perf_counter()
+    for _ in range(5):
+        es.read_population()
+    readback_ms = (time.perf_counter() - t_rb) / 5 * 1e3
 
     if rank == 0:
         value = P * world * args.steps / dt_max
@@ -229,6 +236,11 @@ def main():
                                            "materialises the spectrum, so it moves about 8N. This entry is the whole-loop rate "
                                            "priced at the unfused B_alg (an effective figure that can exceed 1); `roofline` prices "
                                            "the dominant kernel at the bytes that kernel itself has to move"},
+            "pcie_inclusive": {"population_readback_ms": readback_ms,
+                               "bytes": P * (2 * es.D + 1) * 4,
+                               "candidates_per_s_if_read_back_every_generation": P * world / (dt_max / args.steps + readback_ms * 1e-3),
+                               "note": "not `value`: sots_execute_generations keeps every buffer in HBM; hosts cross PCIe only for "
+                                       "the target (4N bytes in) and the final population"},
             "kernels": kernels,
             "roofline_per_kernel": per_kernel,
             "best_fitness_sse": best,

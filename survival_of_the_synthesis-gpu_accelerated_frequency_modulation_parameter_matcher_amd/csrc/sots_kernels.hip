@@ -722,11 +722,16 @@ __device__ __forceinline__ void load_pass_twiddles(float2 *twr, const float2 *__
     }
 }
 
-template <int M, int R, int NS>
+// LAST: the pass's outputs stay in registers instead of going to LDS.  For the last pass
+// (NS * R == M, so k == j and j0 == j) output t of butterfly b is element lane + 64 (b + B t): slot
+// b + B t of x, i.e. afterwards x[s] = Z[lane + 64 s].
+template <int M, int R, int NS, bool LAST = false>
 __device__ __forceinline__ void fft_pass(float2 (&x)[M / kWave], float2 *__restrict__ lds,
                                          const float2 *__restrict__ tw, const float2 *twr, int lane)
 {
     constexpr int E = M / kWave, B = E / R;
+    static_assert(!LAST || NS * R == M, "only the final pass can stay in registers");
+    float2 out[LAST ? E : 1];
     static_assert(E % R == 0, "radix must divide the per-lane element count");
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -741,9 +746,18 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[M / kWave], float2 *__restr
             for (int t = 1; t < R; ++t) v[t] = cmul(v[t], twr ? twr[b * (R - 1) + t - 1] : tw[t * k * stride]);
         }
         Dft<R>::run(v);
-        const int j0 = (j - k) * R + k;
+        if constexpr (LAST) {
 #pragma unroll
-        for (int t = 0; t < R; ++t) lds[lds_pad(j0 + t * NS)] = v[t];
+            for (int t = 0; t < R; ++t) out[b + t * B] = v[t];
+        } else {
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) lds[lds_pad(j0 + t * NS)] = v[t];
+        }
+    }
+    if constexpr (LAST) {
+#pragma unroll
+        for (int sl = 0; sl < E; ++sl) x[sl] = out[sl];
     }
 }
 
@@ -829,9 +843,9 @@ __device__ __forceinline__ void preload_twiddles(float2 (&twr)[tw_count<M>()], c
 
 template <int M>
 __device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], float2 *__restrict__ lds,
-                                            const float2 *__restrict__ tw, const float2 (&twr)[tw_count<M>()], int lane)
+                                            const float2 *__restrict__ tw, const float2 (&twr)[tw_count<M>()], int lane,
+                                            float2 (&x)[M / kWave])
 {
-    float2 x[M / kWave];
 #define SOTS_SYNC() __syncthreads()
 #define SOTS_FIRST(R)                        \
     fft_first_pass<M, R>(q, lds, lane);      \
@@ -842,34 +856,52 @@ __device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], fl
 #define SOTS_NEXT()                          \
     lds_reload<M>(x, lds, lane);             \
     SOTS_SYNC();
+#define SOTS_LAST(R, NS, OFF) fft_pass<M, R, NS, true>(x, lds, tw, tw_in_regs<M>() ? &twr[OFF] : nullptr, lane);
     if constexpr (M == 256) {
-        SOTS_FIRST(4) SOTS_NEXT() SOTS_PASS(4, 4, 0) SOTS_NEXT() SOTS_PASS(4, 16, 3) SOTS_NEXT() SOTS_PASS(4, 64, 6)
+        SOTS_FIRST(4) SOTS_NEXT() SOTS_PASS(4, 4, 0) SOTS_NEXT() SOTS_PASS(4, 16, 3) SOTS_NEXT() SOTS_LAST(4, 64, 6)
     } else if constexpr (M == 512) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 7)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_LAST(8, 64, 7)
     } else if constexpr (M == 1024) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(4, 64, 14) SOTS_NEXT() SOTS_PASS(4, 256, 26)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(4, 64, 14) SOTS_NEXT() SOTS_LAST(4, 256, 26)
     } else if constexpr (M == 2048) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_PASS(4, 512, 0)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_LAST(4, 512, 0)
     } else {
         static_assert(M == 4096, "unsupported FFT length");
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_PASS(8, 512, 0)
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_PASS(8, 512, 0) // 64 registers of Z per lane would spill: the split reads Z from LDS
     }
 #undef SOTS_SYNC
 #undef SOTS_FIRST
 #undef SOTS_PASS
 #undef SOTS_NEXT
+#undef SOTS_LAST
 }
 
-// Real-input split for the pair (k, M-k), 0 <= k < M/2, from Z in LDS:
+// Real-input split for the pair (k, M-k), 0 <= k < M/2:
 //   Ee = (Z[k] + conj Z[M-k]) / 2,  Oo = -i (Z[k] - conj Z[M-k]) / 2,  T = e^{-2 pi i k/N} Oo
 //   X[k] = Ee + T,  X[M-k] = conj(Ee - T)
 // With Z[M] read as Z[0] the same formula gives X[0] = Re Z0 + Im Z0 and the Nyquist bin
 // X[M] = Re Z0 - Im Z0 for k = 0, so no lane takes a different path.  Bin M/2, which no pair
 // covers, is X[M/2] = conj Z[M/2].
+// After the last pass lane l holds z[s] = Z[l + 64 s].  For k = l + 64 q the partner
+// Z[M-k] = Z[(64-l) + 64 (E-1-q)] is slot E-1-q of lane 64-l: one ds_bpermute per dword through
+// the LDS crossbar, no LDS memory and no bank conflicts (this replaces a write of the whole
+// transform to LDS and two reads of it).  Lane 0 pairs with itself one slot further:
+// Z[M - 64 q] = its own slot E-q, and Z[M] = Z[0] for q = 0.
+template <int M> constexpr bool z_in_regs() { return M <= 2048; }
+
 template <int M>
-__device__ __forceinline__ void split_pair(const float2 *__restrict__ lds, float2 w, int k, float2 &xa, float2 &xb)
+__device__ __forceinline__ float2 split_partner(const float2 (&z)[M / kWave], int q, int lane, int partner_addr)
 {
-    const float2 a = lds[lds_pad(k)], bz = lds[lds_pad((M - k) & (M - 1))];
+    constexpr int E = M / kWave;
+    const float2 mine = z[q == 0 ? 0 : E - q];                    // what lane 0 needs
+    const float2 send = z[E - 1 - q];                             // what lane 64-l needs from this lane
+    const float px = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(send.x)));
+    const float py = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(send.y)));
+    return lane == 0 ? mine : make_float2(px, py);
+}
+
+__device__ __forceinline__ void split_pair(float2 a, float2 bz, float2 w, float2 &xa, float2 &xb)
+{
     const float2 b = make_float2(bz.x, -bz.y);
     const float2 ee = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
     const float2 dd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
@@ -926,6 +958,7 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave, H = E / 2;
     __shared__ float2 lds[M + M / 8 + 1];
     const int lane = threadIdx.x;
+    const int partner_addr = ((kWave - lane) & (kWave - 1)) * 4; // ds_bpermute byte address of lane 64-l
     uint32_t ind = blockIdx.x;
     if (ind >= p_len) return;
 
@@ -945,8 +978,10 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
 
     // rows are read 16 bytes per lane: pair index lane + 64 h holds complex points 2(lane+64h), +1
     constexpr int Q = E / 2;
-    float4 wv[WIN ? Q : 1];
-    if constexpr (WIN) {
+    // N = 8192 holds 128 registers of row per lane: no room for a prefetched row or the window
+    constexpr bool LEAN = LOG2N >= 13;
+    float4 wv[WIN && !LEAN ? Q : 1];
+    if constexpr (WIN && !LEAN) {
 #pragma unroll
         for (int h = 0; h < Q; ++h) wv[h] = reinterpret_cast<const float4 *>(window)[lane + kWave * h];
     }
@@ -961,29 +996,40 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     while (true) {
         if constexpr (WIN) {
 #pragma unroll
-            for (int h = 0; h < Q; ++h)
-                x[h] = make_float4(x[h].x * wv[h].x, x[h].y * wv[h].y, x[h].z * wv[h].z, x[h].w * wv[h].w);
+            for (int h = 0; h < Q; ++h) {
+                const float4 w = LEAN ? reinterpret_cast<const float4 *>(window)[lane + kWave * h] : wv[h];
+                x[h] = make_float4(x[h].x * w.x, x[h].y * w.y, x[h].z * w.z, x[h].w * w.w);
+            }
         }
         // the next individual's row is requested before this one is transformed, so its HBM
         // latency hides behind the passes below
         const uint32_t nxt = ind + gridDim.x;
         const bool more = nxt < p_len;
-        float4 y[Q];
-        {
+        float4 y[LEAN ? 1 : Q];
+        if constexpr (!LEAN) {
             const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(more ? nxt : ind) * pitch);
 #pragma unroll
             for (int h = 0; h < Q; ++h) y[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
         }
-        fft_forward<M>(x, lds, tw, twr, lane);
-        const float2 zh = lds[lds_pad(M / 2)];
-        const float2 x_half = make_float2(zh.x, -zh.y); // bin M/2
+        float2 z[E];
+        fft_forward<M>(x, lds, tw, twr, lane, z);
+        // z_in_regs: z[s] = Z[lane + 64 s]; otherwise Z is in LDS in natural order (padded indexing).
+        // Operands of the split for k = lane + 64 q:
+        auto z_k = [&](int q) { return z_in_regs<M>() ? z[q] : lds[lds_pad(lane + kWave * q)]; };
+        auto z_mk = [&](int q) {
+            if constexpr (z_in_regs<M>()) return split_partner<M>(z, q, lane, partner_addr);
+            else return lds[lds_pad((M - (lane + kWave * q)) & (M - 1))];
+        };
+        // bin M/2 = conj Z[M/2]; Z[M/2] = Z[0 + 64 (E/2)] is lane 0's slot E/2, and only lane 0 (k = 0) uses it
+        const float2 zh = z_in_regs<M>() ? z[E / 2] : lds[lds_pad(M / 2)];
+        const float2 x_half = make_float2(zh.x, -zh.y);
         if constexpr (MODE == 0) {
             float2 *__restrict__ row = reinterpret_cast<float2 *>(spectrum + (size_t)ind * (N + 8));
 #pragma unroll
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
                 float2 xa, xb;
-                split_pair<M>(lds, w_split[q], k, xa, xb);
+                split_pair(z_k(q), z_mk(q), w_split[q], xa, xb);
                 row[k] = xa;
                 row[M - k] = xb; // k = 0 lands on the Nyquist bin M
             }
@@ -994,7 +1040,7 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
                 float2 xa, xb;
-                split_pair<M>(lds, w_split[q], k, xa, xb);
+                split_pair(z_k(q), z_mk(q), w_split[q], xa, xb);
                 if (k == 0) xb = x_half; // the fitness skips the Nyquist bin and needs bin M/2
                 acc += bin_error(xa, tgt_a[q], inv_n, inv_wf);
                 acc += bin_error(xb, tgt_b[q], inv_n, inv_wf);
@@ -1004,8 +1050,14 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
         }
         if (!more) break;
         __syncthreads();
+        if constexpr (LEAN) {
+            const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)nxt * pitch);
 #pragma unroll
-        for (int h = 0; h < Q; ++h) x[h] = y[h];
+            for (int h = 0; h < Q; ++h) x[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
+        } else {
+#pragma unroll
+            for (int h = 0; h < Q; ++h) x[h] = y[h];
+        }
         ind = nxt;
     }
 }
