@@ -949,6 +949,9 @@ __device__ __forceinline__ float wave_sum(float v)
 // WIN: multiply by the fp32 window while loading (the generation loop then skips both the
 // window pass and any window work in the synthesis kernel; the product is the same single
 // fp32 rounding either way).
+#ifndef SOTS_FFT_NOPREFETCH_FROM
+#define SOTS_FFT_NOPREFETCH_FROM 13
+#endif
 template <int LOG2N, int MODE, bool WIN>
 __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
@@ -965,12 +968,22 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     // per-lane constants of the split / fitness step, loaded once (nothing but the audio
     // prefetch is in flight inside the loop, so its waits never drain the prefetch)
     float2 w_split[H];
-    float tgt_a[H], tgt_b[H];
 #pragma unroll
-    for (int q = 0; q < H; ++q) {
-        const int k = lane + kWave * q;
-        w_split[q] = tw[k];
-        if constexpr (MODE == 1) {
+    for (int q = 0; q < H; ++q) w_split[q] = tw[lane + kWave * q];
+    // the target spectrum sits in LDS (2N bytes): eight registers fewer than holding this lane's
+    // bins, which is what keeps N = 1024 at three wavefronts per SIMD with two rows in flight
+    // (for N >= 4096 the LDS copy would cost occupancy instead: those keep their bins in registers)
+    constexpr bool TGT_LDS = MODE == 1 && LOG2N <= 11;
+    __shared__ float tgt_s[TGT_LDS ? M + 1 : 1];
+    float tgt_a[MODE == 1 && !TGT_LDS ? H : 1], tgt_b[MODE == 1 && !TGT_LDS ? H : 1];
+    if constexpr (TGT_LDS) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) tgt_s[lane + kWave * q] = target[lane + kWave * q];
+        __syncthreads();
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+            const int k = lane + kWave * q;
             tgt_a[q] = target[k];
             tgt_b[q] = target[k == 0 ? M / 2 : M - k];
         }
@@ -987,32 +1000,28 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     }
     float2 twr[tw_count<M>()];
     preload_twiddles<M>(twr, tw, lane);
-    float4 x[Q];
-    {
-        const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)ind * pitch);
+    // Row buffers rotate (no copies): DEPTH rows are in flight beside the one being transformed.
+    // Short rows (N <= 1024) use DEPTH = 2 - a row's transform is shorter than the loaded memory
+    // latency and the registers are there (168 = three wavefronts per SIMD); N = 8192 has no
+    // register left for any.
+    constexpr int DEPTH = LOG2N >= SOTS_FFT_NOPREFETCH_FROM ? 0 : LOG2N <= 10 ? 2 : 1;
+    auto request = [&](float4 (&dst)[Q], uint32_t r) { // rows past the end re-read the last valid one
+        const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(r < p_len ? r : ind) * pitch);
 #pragma unroll
-        for (int h = 0; h < Q; ++h) x[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
-    }
-    while (true) {
+        for (int h = 0; h < Q; ++h) dst[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
+    };
+    // transforms the row in `cur` (individual `ind`) after requesting row ind + (DEPTH) * grid into `fill`
+    auto process = [&](float4 (&cur)[Q], float4 (&fill)[Q]) {
         if constexpr (WIN) {
 #pragma unroll
             for (int h = 0; h < Q; ++h) {
                 const float4 w = LEAN ? reinterpret_cast<const float4 *>(window)[lane + kWave * h] : wv[h];
-                x[h] = make_float4(x[h].x * w.x, x[h].y * w.y, x[h].z * w.z, x[h].w * w.w);
+                cur[h] = make_float4(cur[h].x * w.x, cur[h].y * w.y, cur[h].z * w.z, cur[h].w * w.w);
             }
         }
-        // the next individual's row is requested before this one is transformed, so its HBM
-        // latency hides behind the passes below
-        const uint32_t nxt = ind + gridDim.x;
-        const bool more = nxt < p_len;
-        float4 y[LEAN ? 1 : Q];
-        if constexpr (!LEAN) {
-            const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(more ? nxt : ind) * pitch);
-#pragma unroll
-            for (int h = 0; h < Q; ++h) y[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
-        }
+        if constexpr (DEPTH > 0) request(fill, ind + DEPTH * gridDim.x);
         float2 z[E];
-        fft_forward<M>(x, lds, tw, twr, lane, z);
+        fft_forward<M>(cur, lds, tw, twr, lane, z);
         // z_in_regs: z[s] = Z[lane + 64 s]; otherwise Z is in LDS in natural order (padded indexing).
         // Operands of the split for k = lane + 64 q:
         auto z_k = [&](int q) { return z_in_regs<M>() ? z[q] : lds[lds_pad(lane + kWave * q)]; };
@@ -1042,23 +1051,46 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
                 float2 xa, xb;
                 split_pair(z_k(q), z_mk(q), w_split[q], xa, xb);
                 if (k == 0) xb = x_half; // the fitness skips the Nyquist bin and needs bin M/2
-                acc += bin_error(xa, tgt_a[q], inv_n, inv_wf);
-                acc += bin_error(xb, tgt_b[q], inv_n, inv_wf);
+                acc += bin_error(xa, TGT_LDS ? tgt_s[k] : tgt_a[q], inv_n, inv_wf);
+                acc += bin_error(xb, TGT_LDS ? tgt_s[k == 0 ? M / 2 : M - k] : tgt_b[q], inv_n, inv_wf);
             }
             acc = wave_sum(acc);
             if (lane == 0) fitness[ind] = acc;
         }
-        if (!more) break;
-        __syncthreads();
-        if constexpr (LEAN) {
-            const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)nxt * pitch);
+        ind += gridDim.x;
+        __syncthreads(); // single-wavefront workgroup: orders this row's LDS reads before the next row's writes
+        return ind < p_len;
+    };
+    if constexpr (DEPTH == 0) {
+        float4 b0[Q];
+        do request(b0, ind);
+        while (process(b0, b0));
+    } else if constexpr (DEPTH == 1 && LOG2N >= 12) {
+        // one copy of the loop body and a register copy per row: the two-body rotation below
+        // needs more registers than N = 4096 has
+        float4 b0[Q], b1[Q];
+        request(b0, ind);
+        while (process(b0, b1)) {
 #pragma unroll
-            for (int h = 0; h < Q; ++h) x[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
-        } else {
-#pragma unroll
-            for (int h = 0; h < Q; ++h) x[h] = y[h];
+            for (int h = 0; h < Q; ++h) b0[h] = b1[h];
         }
-        ind = nxt;
+    } else if constexpr (DEPTH == 1) {
+        float4 b0[Q], b1[Q];
+        request(b0, ind);
+        while (true) {
+            if (!process(b0, b1)) break;
+            if (!process(b1, b0)) break;
+        }
+    } else {
+        float4 b0[Q], b1[Q], b2[Q];
+        request(b0, ind);
+        asm volatile("" ::: "memory"); // keep the two requests in this order (the loop's waits count on it)
+        request(b1, ind + gridDim.x);
+        while (true) {
+            if (!process(b0, b2)) break;
+            if (!process(b1, b0)) break;
+            if (!process(b2, b1)) break;
+        }
     }
 }
 
