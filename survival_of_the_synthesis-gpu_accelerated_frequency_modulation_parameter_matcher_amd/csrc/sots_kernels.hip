@@ -245,7 +245,7 @@ __device__ __forceinline__ void wrap_both(float &p)
     p = __uint_as_float(min(min(__float_as_uint(bc.x), __float_as_uint(bc.y)), __float_as_uint(p)));
 }
 
-__device__ __forceinline__ void load_wavetable(float *__restrict__ tab, const float *__restrict__ wavetable)
+__device__ __forceinline__ void request_wavetable(float *__restrict__ tab, const float *__restrict__ wavetable)
 {
     // global -> LDS directly (global_load_lds_dwordx4): one wavefront instruction lands 1 KiB at a
     // wavefront-uniform LDS base + lane * 16 B, no registers in between, all 128 in flight at once
@@ -255,6 +255,10 @@ __device__ __forceinline__ void load_wavetable(float *__restrict__ tab, const fl
     constexpr uint32_t kChunk = kWave * 4; // floats per instruction
     for (uint32_t ch = wave; ch < kWavetableSize / kChunk; ch += waves)
         __builtin_amdgcn_global_load_lds(wavetable + ch * kChunk + lane * 4u, (lds_ptr_t)(tab + ch * kChunk), 16, 0, 0);
+}
+// ... and the wait for it, after whatever else the kernel can start meanwhile
+__device__ __forceinline__ void wavetable_ready()
+{
     __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the copies have landed
     __syncthreads();
 }
@@ -313,7 +317,8 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
     constexpr int U = kSynthUnroll;
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
-    load_wavetable(tab, wavetable);
+    request_wavetable(tab, wavetable);
+    bool table_pending = true; // the first tile's parameters are fetched while the table is on its way
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
@@ -357,6 +362,10 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
 #pragma unroll
         for (int j = 0; j < J; ++j) in_range = in_range && inc0[j] >= 0.0f && inc0[j] < kWf;
         const bool free_unclamped = __all(in_range);
+        if (table_pending) {
+            wavetable_ready();
+            table_pending = false;
+        }
         SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave);
 
         auto run = [&](auto unclamped_tag) {
@@ -471,6 +480,7 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
         if (free_unclamped) run(std::true_type{});
         else run(std::false_type{});
     }
+    if (table_pending) wavetable_ready(); // a workgroup without a tile must not end with copies in flight
 }
 
 // ---- 2-operator voice, a modulator wavefront and a carrier wavefront per 64 individuals ------
@@ -495,7 +505,8 @@ __global__ __launch_bounds__(kDuoMaxPairs * 2 * kWave) void k_synth_duo(const fl
     __shared__ float tab[kWavetableSize];
     __shared__ float4 xinc_all[kDuoMaxPairs][2][kDuoBlock / 4][kWave]; // 4 KiB per pair
     __shared__ float4 tile_all[kDuoMaxPairs][kWave * kDuoTileChunks];   // 4 KiB per pair
-    load_wavetable(tab, wavetable);
+    request_wavetable(tab, wavetable);
+    wavetable_ready();
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
     const uint32_t pairs = blockDim.x / (2 * kWave);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
