@@ -960,9 +960,6 @@ __device__ __forceinline__ float wave_sum(float v)
 // WIN: multiply by the fp32 window while loading (the generation loop then skips both the
 // window pass and any window work in the synthesis kernel; the product is the same single
 // fp32 rounding either way).
-#ifndef SOTS_FFT_NOPREFETCH_FROM
-#define SOTS_FFT_NOPREFETCH_FROM 13
-#endif
 template <int LOG2N, int MODE, bool WIN>
 __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
@@ -1015,7 +1012,7 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     // Short rows (N <= 1024) use DEPTH = 2 - a row's transform is shorter than the loaded memory
     // latency and the registers are there (168 = three wavefronts per SIMD); N = 8192 has no
     // register left for any.
-    constexpr int DEPTH = LOG2N >= SOTS_FFT_NOPREFETCH_FROM ? 0 : LOG2N <= 10 ? 2 : 1;
+    constexpr int DEPTH = LEAN ? 0 : LOG2N <= 10 ? 2 : 1;
     auto request = [&](float4 (&dst)[Q], uint32_t r) { // rows past the end re-read the last valid one
         const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(r < p_len ? r : ind) * pitch);
 #pragma unroll
