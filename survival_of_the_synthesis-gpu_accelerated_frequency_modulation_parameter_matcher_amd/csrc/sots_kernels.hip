@@ -191,14 +191,13 @@ __device__ __forceinline__ float4 nt_load4(const float4 *p)
 // The oscillator phases are fp32 running sums with a conditional wrap per sample, so a
 // voice is serial in the sample index and cannot be split over lanes without changing the
 // rounding (and with it table indices and spectra).  The 32768-entry wavetable (128 KiB)
-// lives in LDS, one workgroup per CU, which leaves 32 KiB of LDS.  Two kernels:
+// lives in LDS, one workgroup per CU, which leaves 32 KiB of LDS.  One kernel:
 //   k_synth      every voice, one lane per individual.  A voice is J parallel chains of OPS
 //                operators in series; operator s of block k-s runs in loop trip k (software
 //                pipeline over blocks of 8 samples, two alternating register sets, no copies),
 //                so no table read is waited for in the trip that issues it.  Finished samples
 //                are parked in a swizzled LDS tile and leave as whole 128-byte lines.
-//   k_synth_duo  2-operator voice for small populations (at most two wavefronts per CU):
-//                modulator and carrier recurrences in separate wavefronts.
+//                For small populations a series chain is cut into two wavefronts (SPLIT, below).
 // With one wavefront per SIMD every vector instruction costs four cycles, whatever it does, so
 // the instruction count per sample is what the loop time follows (in-kernel s_memtime stamps,
 // -DSOTS_STAMP): branch-free wraps (below), packed v_pk_* arithmetic for the per-sample
@@ -307,7 +306,15 @@ template <> struct VoiceShape<SOTS_SYNTH_TRIPLE_PAR> { static constexpr int J = 
 
 template <int V> using ic = std::integral_constant<int, V>;
 
-template <int KIND>
+// SPLIT > 0 (series voices, at most two wavefronts' worth of individuals per CU): the chain is cut in
+// front of operator SPLIT and runs in TWO wavefronts per 64 individuals, so that all four SIMDs of
+// a CU work when the population is small.  The FRONT wavefront runs operators 0..SPLIT-1 and hands
+// c * (t * mul + off) - operator SPLIT's phase increments, the same unfused arithmetic - over
+// through LDS, one 8-sample block per trip; the BACK wavefront runs operators SPLIT..OPS-1 and
+// the tile.  Both execute the same sequence of trips with one workgroup barrier per trip: the
+// block handed over in trip k is consumed in trip k+1, exactly when the one-wavefront pipeline
+// would read it from registers, and the two hand-over buffers alternate with the block parity.
+template <int KIND, int SPLIT>
 __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__restrict__ values,
                                                                const float *__restrict__ wavetable,
                                                                float *__restrict__ audio, SynthParams sp,
@@ -315,13 +322,21 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
 {
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
     constexpr int U = kSynthUnroll;
+    static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
     request_wavetable(tab, wavetable);
     bool table_pending = true; // the first tile's parameters are fetched while the table is on its way
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
-    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    // SPLIT: wavefronts [0, pairs) are BACK, [pairs, 2 pairs) FRONT of the same 64 individuals
+    const uint32_t pairs = SPLIT ? blockDim.x / (2 * kWave) : blockDim.x / kWave;
+    const bool front = SPLIT && wave_id >= pairs;
+    const uint32_t wave = front ? wave_id - pairs : wave_id; // which 64 individuals of the workgroup's tile
     float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
+    // hand-over buffers [parity][U/4][lane] of 16 bytes behind the (at most two) tiles of a cut kernel
+    float4 *__restrict__ xbuf = stage_all + 2 * kWave * kStageChunks + wave * (2 * (U / 4) * kWave);
     // write side: lane = row; chunk q of the row lives in slot q ^ (row & 7)
     float4 *__restrict__ wr = stage + lane * kStageChunks;
     const uint32_t l7 = lane & 7u;
@@ -330,7 +345,8 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
     const float4 *__restrict__ rd = stage + r8 * kStageChunks + (l7 ^ r8);
     const uint32_t lane_off = r8 * pitch + 4u * l7; // floats, relative to the group's first row
 
-    for (uint32_t base = blockIdx.x * blockDim.x; base < p_len; base += gridDim.x * blockDim.x) {
+    const uint32_t rows_per_block = pairs * kWave;
+    for (uint32_t base = blockIdx.x * rows_per_block; base < p_len; base += gridDim.x * rows_per_block) {
         const uint32_t row0 = base + wave * kWave; // first row of this wavefront
         const uint32_t ind = row0 + lane < p_len ? row0 + lane : p_len - 1u;
         const bool full = row0 + kWave <= p_len; // every row of the tile exists
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
             wavetable_ready();
             table_pending = false;
         }
-        SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave);
+        SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave_id);
 
         auto run = [&](auto unclamped_tag) {
             constexpr bool UNCLAMPED = decltype(unclamped_tag)::value;
@@ -380,6 +396,9 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
             // operator S on the block of parity Q
             auto op = [&](auto s_tag, auto q_tag) {
                 constexpr int S = decltype(s_tag)::value, Q = decltype(q_tag)::value;
+                if constexpr (SPLIT > 0) {
+                    if (front != (S < SPLIT)) return; // the other wavefront's operator
+                }
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     if constexpr (S == 0) {
@@ -393,9 +412,17 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
                         // phase increments, two samples per packed instruction (v_pk_mul_f32,
                         // v_pk_add_f32, v_pk_mul_f32: the reference's mul, add, mul, unfused)
                         v2f_t inc[U / 2];
+                        if constexpr (SPLIT > 0 && S == SPLIT) { // handed over by the front wavefront
 #pragma unroll
-                        for (int u = 0; u < U; u += 2)
-                            inc[u / 2] = (v2f_t{T[S - 1][Q][j][u], T[S - 1][Q][j][u + 1]} * mul[S][j] + off[S][j]) * c;
+                            for (int u = 0; u < U; u += 4) {
+                                const float4 q = xbuf[(Q * (U / 4) + u / 4) * kWave + lane];
+                                inc[u / 2] = v2f_t{q.x, q.y}, inc[u / 2 + 1] = v2f_t{q.z, q.w};
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; u += 2)
+                                inc[u / 2] = (v2f_t{T[S - 1][Q][j][u], T[S - 1][Q][j][u + 1]} * mul[S][j] + off[S][j]) * c;
+                        }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             T[S][Q][j][u] = tab_at(tab, pos[S][j]);
@@ -404,10 +431,21 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
                         }
                     }
                 }
+                if constexpr (SPLIT > 0 && S == SPLIT - 1) { // front: hand operator SPLIT's increments over
+#pragma unroll
+                    for (int u = 0; u < U; u += 4) {
+                        const v2f_t lo = (v2f_t{T[S][Q][0][u], T[S][Q][0][u + 1]} * mul[SPLIT][0] + off[SPLIT][0]) * c;
+                        const v2f_t hi = (v2f_t{T[S][Q][0][u + 2], T[S][Q][0][u + 3]} * mul[SPLIT][0] + off[SPLIT][0]) * c;
+                        xbuf[(Q * (U / 4) + u / 4) * kWave + lane] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                }
             };
             // samples ip..ip+7 (the block of parity Q) leave
             auto emit = [&](auto q_tag, uint32_t ip) {
                 constexpr int Q = decltype(q_tag)::value;
+                if constexpr (SPLIT > 0) {
+                    if (front) return;
+                }
                 float y[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -457,6 +495,7 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
                 if constexpr (SMIN <= 2 && 2 <= SMAX && 2 < OPS) op(ic<2>{}, ic<Q>{});
                 if constexpr (SMIN <= 3 && 3 <= SMAX && 3 < OPS) op(ic<3>{}, ic<Q ^ 1>{});
                 if constexpr (SMAX == OPS) emit(ic<Q ^ (OPS & 1)>{}, (k - OPS) * U);
+                if constexpr (SPLIT > 0) __syncthreads(); // the block handed over in this trip is read in the next
             };
             const uint32_t nb = n / U; // even and >= 64
             constexpr int K0 = (OPS + 1) & ~1; // first trip with every stage busy, rounded to even
@@ -481,150 +520,6 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
         else run(std::false_type{});
     }
     if (table_pending) wavetable_ready(); // a workgroup without a tile must not end with copies in flight
-}
-
-// ---- 2-operator voice, a modulator wavefront and a carrier wavefront per 64 individuals ------
-// The modulator phase never depends on the carrier, so the two recurrences run in different
-// wavefronts: the HELPER advances the modulator phase, reads
-// the table and hands c * (t * mod + fc) - the carrier's phase increment - over through LDS,
-// eight samples at a time; the CARRIER advances its phase, reads the table, scales and parks
-// the samples in a swizzled [64 rows][16 samples] tile that it flushes with stores in which four
-// neighbouring lanes cover 64 contiguous bytes of one row.  Each per-sample operation is the
-// reference's, in its order, so the result is bit-identical to k_synth<2OP>.  Used when a CU's share is at most 128
-// individuals: each wavefront then carries half the instructions (in-kernel 80 instead of 100
-// cycles per sample); with four pairs per CU the barrier every 8 samples costs more than that.
-constexpr int kDuoMaxPairs = 4;                // carrier/helper pairs per workgroup
-constexpr int kDuoBlock = 8;                   // samples per hand-over
-constexpr int kDuoTileChunks = 4;              // 16-byte chunks per staged row (16 samples)
-
-__global__ __launch_bounds__(kDuoMaxPairs * 2 * kWave) void k_synth_duo(const float *__restrict__ values,
-                                                                         const float *__restrict__ wavetable,
-                                                                         float *__restrict__ audio, SynthParams sp,
-                                                                         uint32_t p_len, uint32_t n, uint32_t pitch)
-{
-    __shared__ float tab[kWavetableSize];
-    __shared__ float4 xinc_all[kDuoMaxPairs][2][kDuoBlock / 4][kWave]; // 4 KiB per pair
-    __shared__ float4 tile_all[kDuoMaxPairs][kWave * kDuoTileChunks];   // 4 KiB per pair
-    request_wavetable(tab, wavetable);
-    wavetable_ready();
-    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE;
-    const uint32_t pairs = blockDim.x / (2 * kWave);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const bool helper = wave >= pairs;
-    const uint32_t pair = helper ? wave - pairs : wave;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    float4(*__restrict__ xinc)[kDuoBlock / 4][kWave] = xinc_all[pair];
-    float4 *__restrict__ tile = tile_all[pair];
-    // tile write side: lane = row, chunk q of the row in slot q ^ ((row >> 1) & 3) (conflict-free
-    // for the 8-lane groups of ds_write_b128 on a 64-byte row); read side: lane = (row & 15, chunk)
-    float4 *__restrict__ wr = tile + lane * kDuoTileChunks;
-    const uint32_t wswz = (lane >> 1) & 3u;
-    const uint32_t r16 = lane >> 2, ch = lane & 3u;
-    const float4 *__restrict__ rd = tile + r16 * kDuoTileChunks + (ch ^ ((r16 >> 1) & 3u));
-    const uint32_t lane_off = r16 * pitch + 4u * ch;
-
-    for (uint32_t base = blockIdx.x * pairs * kWave; base < p_len; base += gridDim.x * pairs * kWave) {
-        const uint32_t row0 = base + pair * kWave;
-        const uint32_t ind = row0 + lane < p_len ? row0 + lane : p_len - 1u;
-        const float4 v = *reinterpret_cast<const float4 *>(values + (size_t)ind * 4);
-        const float p0 = sp.pmin[0] + v.x * (sp.pmax[0] - sp.pmin[0]);
-        const float p1 = sp.pmin[1] + v.y * (sp.pmax[1] - sp.pmin[1]);
-        const float fc = sp.pmin[2] + v.z * (sp.pmax[2] - sp.pmin[2]);
-        const float amp = sp.pmin[3] + v.w * (sp.pmax[3] - sp.pmin[3]);
-        const float mod = p0 * p1, inc1 = c * p0;
-        const bool full = row0 + kWave <= p_len;
-        SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave);
-        float pos = 0.0f; // the helper's modulator phase or the carrier's phase
-        float ta[kDuoBlock], tb[kDuoBlock];
-
-        auto gather = [&](float (&t)[kDuoBlock]) { // helper: table reads of one block
-#pragma unroll
-            for (int u = 0; u < kDuoBlock; ++u) {
-                t[u] = tab_at(tab, pos);
-                pos += inc1;
-                wrap_hi(pos);
-            }
-        };
-        auto hand_over = [&](const float (&t)[kDuoBlock], uint32_t buf) { // helper: increments of one block
-#pragma unroll
-            for (int j = 0; j < kDuoBlock / 4; ++j) {
-                const v2f_t lo = (v2f_t{t[4 * j + 0], t[4 * j + 1]} * mod + fc) * c; // packed mul, add, mul
-                const v2f_t hi = (v2f_t{t[4 * j + 2], t[4 * j + 3]} * mod + fc) * c;
-                xinc[buf][j][lane] = make_float4(lo.x, lo.y, hi.x, hi.y);
-            }
-        };
-        auto advance = [&](float (&y)[kDuoBlock], uint32_t buf) { // carrier: one block of the recurrence
-            float inc[kDuoBlock];
-#pragma unroll
-            for (int j = 0; j < kDuoBlock / 4; ++j) {
-                const float4 q = xinc[buf][j][lane];
-                inc[4 * j + 0] = q.x, inc[4 * j + 1] = q.y, inc[4 * j + 2] = q.z, inc[4 * j + 3] = q.w;
-            }
-#pragma unroll
-            for (int u = 0; u < kDuoBlock; ++u) {
-                y[u] = tab_at(tab, pos);
-                pos += inc[u];
-                wrap_both(pos);
-            }
-        };
-        auto emit = [&](const float (&y)[kDuoBlock], uint32_t ip) { // carrier: samples ip..ip+7 leave
-            const uint32_t c0 = (ip >> 2) & (kDuoTileChunks - 1);
-            wr[c0 ^ wswz] = make_float4(y[0] * amp, y[1] * amp, y[2] * amp, y[3] * amp);
-            wr[(c0 + 1) ^ wswz] = make_float4(y[4] * amp, y[5] * amp, y[6] * amp, y[7] * amp);
-            if (c0 == kDuoTileChunks - 2) { // 16 samples parked: flush the tile
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-                const uint32_t i0 = ip + kDuoBlock - 4 * kDuoTileChunks;
-                float *__restrict__ grp = audio + (size_t)row0 * pitch + i0 + lane_off;
-                constexpr int G = 16 * kDuoTileChunks; // slots per group of 16 rows
-                const size_t g16 = (size_t)16u * pitch;
-                if (full) {
-                    const float4 q0 = rd[0 * G], q1 = rd[1 * G], q2 = rd[2 * G], q3 = rd[3 * G];
-                    *reinterpret_cast<float4 *>(grp + 0 * g16) = q0;
-                    *reinterpret_cast<float4 *>(grp + 1 * g16) = q1;
-                    *reinterpret_cast<float4 *>(grp + 2 * g16) = q2;
-                    *reinterpret_cast<float4 *>(grp + 3 * g16) = q3;
-                } else { // last, partly filled tile of the population
-#pragma unroll 1
-                    for (uint32_t it = 0; it < 4; ++it)
-                        if (row0 + 16u * it + r16 < p_len) *reinterpret_cast<float4 *>(grp + it * g16) = rd[it * G];
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-            }
-        };
-
-        // Step k: the helper hands over block k+1 (read from the table during step k-1) and
-        // reads the table for block k+2; the carrier advances block k and sends block k-1 out.
-        // Register sets a/b alternate, so the loop body covers two blocks.  n is a multiple of 16.
-        if (helper) {
-            gather(ta);
-            hand_over(ta, 0);
-            gather(tb);
-        }
-        __syncthreads();
-        for (uint32_t i = 0; i < n; i += 2 * kDuoBlock) {
-            if (helper) {
-                hand_over(tb, 1);                              // block k+1
-                if (i + 2 * kDuoBlock < n) gather(ta);         // block k+2
-            } else {
-                advance(ta, 0);                                // block k
-                if (i > 0) emit(tb, i - kDuoBlock);            // block k-1
-            }
-            __syncthreads();
-            if (helper) {
-                if (i + 2 * kDuoBlock < n) {
-                    hand_over(ta, 0);                          // block k+2
-                    gather(tb);                                // block k+3
-                }
-            } else {
-                advance(tb, 1);                                // block k+1
-                emit(ta, i);                                   // block k
-            }
-            __syncthreads();
-        }
-        if (!helper) emit(tb, n - kDuoBlock);
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1486,27 +1381,30 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     const uint32_t n = 1u << log2n;
     const uint32_t cus = num_cus ? num_cus : 256;
     // The 128 KiB table allows one workgroup per CU, so the workgroup is sized to the CU's share
-    // of the population, up to one wavefront per SIMD; larger populations loop.
+    // of the population, up to one wavefront per SIMD; larger populations loop.  Up to two
+    // wavefronts' worth per CU, a series voice is cut into two wavefronts per 64 individuals.
     const uint32_t share = (p + cus - 1) / cus;
     uint32_t waves = (share + kWave - 1) / kWave;
-    static const bool use_duo = [] {
-        const char *e = getenv("SOTS_SYNTH_DUO"); // 0: never the two-wavefront kernel (A/B profiling)
+    waves = waves < 1 ? 1 : waves > (uint32_t)kSynthWaves ? (uint32_t)kSynthWaves : waves;
+    static const bool allow_cut = [] {
+        const char *e = getenv("SOTS_SYNTH_CUT"); // 0: never cut the chain (A/B profiling)
         return e ? atoi(e) != 0 : true;
     }();
-    if (kind == SOTS_SYNTH_2OP && use_duo && waves <= 2) {
-        const uint32_t pairs = waves < 1 ? 1 : waves;
-        k_synth_duo<<<grid_for(p, pairs * kWave, cus), pairs * 2 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);
-        return hipGetLastError();
-    }
-    waves = waves < 1 ? 1 : waves > (uint32_t)kSynthWaves ? (uint32_t)kSynthWaves : waves;
-    const uint32_t threads = waves * kWave, grid = grid_for(p, threads, cus);
+    const bool cut = allow_cut && waves <= 2 && kind != SOTS_SYNTH_TRIPLE_PAR;
+    const uint32_t threads = (cut ? 2 : 1) * waves * kWave, grid = grid_for(p, waves * kWave, cus);
+#define SOTS_SYNTH_CASE(K, S)                                                                            \
+    case K:                                                                                              \
+        if (cut) k_synth<K, S><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);     \
+        else k_synth<K, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);         \
+        break;
     switch (kind) {
-    case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
-    case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
-    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
-    case SOTS_SYNTH_4OP_SERIES: k_synth<SOTS_SYNTH_4OP_SERIES><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+        SOTS_SYNTH_CASE(SOTS_SYNTH_2OP, 1)
+        SOTS_SYNTH_CASE(SOTS_SYNTH_3OP_SERIES, 2)
+        SOTS_SYNTH_CASE(SOTS_SYNTH_4OP_SERIES, 2)
+    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
     default: return hipErrorInvalidValue;
     }
+#undef SOTS_SYNTH_CASE
     return hipGetLastError();
 }
 

@@ -121,7 +121,7 @@ def test_synthesise_bitexact(pkg, O, kind, log2n):
 
 def test_synthesise_two_op_large_population_uses_lane_per_individual_kernel(pkg, O):
     """Above 128 individuals per CU the 2-op voice runs k_synth (one lane per individual, four
-    wavefronts per workgroup, looping over tiles) instead of the two-wavefront kernel; rows are
+    wavefronts per workgroup, looping over tiles) instead of the chain cut into two wavefronts; rows are
     spot-checked against the oracle."""
     parents, offspring = 16640, 49920          # P = 66560 = 260 per CU on 256 CUs
     es, _ = make_pair(pkg, O, parents, offspring, 0, 10)

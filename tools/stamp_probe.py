@@ -1,5 +1,5 @@
 """Diagnostic: in-kernel shader cycles of the synthesis loop (needs a -DSOTS_STAMP build).
-usage: SOTS_LIB_PATH=variants/libsots_stamp.so [SOTS_SYNTH_STAGED=1|SOTS_SYNTH_DUO=1] python tools/stamp_probe.py P [log2n]"""
+usage: SOTS_LIB_PATH=variants/libsots_stamp.so [SOTS_SYNTH_CUT=0|1] python tools/stamp_probe.py P [log2n]"""
 import ctypes as C, importlib, sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
