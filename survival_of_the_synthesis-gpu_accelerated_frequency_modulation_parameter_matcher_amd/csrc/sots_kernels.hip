@@ -1022,6 +1022,210 @@ __global__ __launch_bounds__(kWave) void k_fitness(const float *__restrict__ spe
     }
 }
 
+// ---- long rows: one WORKGROUP per row --------------------------------------------------------
+// From N = 4096 a row no longer fits one wavefront's registers next to a prefetched row (the
+// wavefront-per-row kernel runs one wavefront per SIMD there, and spills at N = 8192).  Here T
+// threads share a row, M / T complex points each, so a thread holds 8 or 16 points and four
+// wavefronts per SIMD stay resident.  Same Stockham passes and real-input split; slot s of a
+// thread is element t + T s, loaded 8 bytes per thread (coalesced), exchanges through the padded
+// LDS buffer with workgroup barriers.  The fitness sum adds the wavefronts' DPP sums in wavefront
+// order; k_fitness_wg, the stage-separated twin, uses the same bin -> thread map and order, so the
+// fused and the stage-separated loop still give bit-identical fitness.
+template <int LOG2N> constexpr int wg_threads() { return LOG2N <= 11 ? 128 : 256; }
+
+template <int M, int R, int NS, int T>
+__device__ __forceinline__ void wg_pass(float2 (&x)[M / T], float2 *__restrict__ lds, const float2 *__restrict__ tw,
+                                        const float2 *twr, int tid)
+{
+    constexpr int E = M / T, B = E / R;
+    static_assert(E % R == 0, "radix must divide the per-thread element count");
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int j = tid + T * b;
+        const int k = j & (NS - 1);
+        float2 v[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) v[t] = x[b + t * B];
+        if constexpr (NS > 1) {
+            constexpr int stride = (2 * M) / (NS * R);
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], twr ? twr[b * (R - 1) + t - 1] : tw[t * k * stride]);
+        }
+        Dft<R>::run(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int t = 0; t < R; ++t) lds[lds_pad(j0 + t * NS)] = v[t];
+    }
+}
+
+template <int M, int R, int NS, int T>
+__device__ __forceinline__ void wg_pass_twiddles(float2 *twr, const float2 *__restrict__ tw, int tid)
+{
+    constexpr int E = M / T, B = E / R, stride = (2 * M) / (NS * R);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int k = (tid + T * b) & (NS - 1);
+#pragma unroll
+        for (int t = 1; t < R; ++t) twr[b * (R - 1) + t - 1] = tw[t * k * stride];
+    }
+}
+
+// per-thread pass twiddles kept in registers (M = 4096 would need 42 complex values: from the table)
+template <int M> constexpr int wg_tw_count() { return M == 1024 ? 19 : M == 2048 ? 20 : 1; }
+
+// minimum wavefronts per SIMD asked of the register allocator: N = 2048 fits 168 registers (three);
+// the longer rows lose more to spills than they gain (measured), so they are left alone
+template <int LOG2N> constexpr int wg_waves_per_simd() { return LOG2N <= 11 ? 3 : 1; }
+
+template <int LOG2N, int MODE, bool WIN>
+__global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) void k_fft_wg(const float *__restrict__ audio,
+                                                                float *__restrict__ spectrum,
+                                                                const float *__restrict__ target,
+                                                                float *__restrict__ fitness,
+                                                                const float2 *__restrict__ tw,
+                                                                const float *__restrict__ window, uint32_t p_len,
+                                                                float inv_n, float inv_wf, uint32_t pitch)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, T = wg_threads<LOG2N>(), E = M / T, H = E / 2, W = T / kWave;
+    static_assert(M == 1024 || M == 2048 || M == 4096, "workgroup-per-row FFT is for N >= 2048");
+    __shared__ float2 lds[M + M / 8 + 1];
+    __shared__ float tgt_s[MODE == 1 ? M + 1 : 1];
+    __shared__ float red[W];
+    const int tid = threadIdx.x;
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) tgt_s[tid + T * q] = target[tid + T * q];
+    }
+    float2 w_split[H], wv[WIN ? E : 1];
+#pragma unroll
+    for (int q = 0; q < H; ++q) w_split[q] = tw[tid + T * q];
+    if constexpr (WIN) {
+#pragma unroll
+        for (int sl = 0; sl < E; ++sl) wv[sl] = reinterpret_cast<const float2 *>(window)[tid + T * sl];
+    }
+    constexpr bool TWR = M <= 2048;
+    float2 twr[wg_tw_count<M>()];
+    if constexpr (M == 1024) {
+        wg_pass_twiddles<M, 8, 8, T>(&twr[0], tw, tid);
+        wg_pass_twiddles<M, 4, 64, T>(&twr[7], tw, tid);
+        wg_pass_twiddles<M, 4, 256, T>(&twr[13], tw, tid);
+    } else if constexpr (M == 2048) {
+        wg_pass_twiddles<M, 8, 8, T>(&twr[0], tw, tid);
+        wg_pass_twiddles<M, 8, 64, T>(&twr[7], tw, tid);
+        wg_pass_twiddles<M, 4, 512, T>(&twr[14], tw, tid);
+    } else {
+        twr[0] = make_float2(0.f, 0.f);
+    }
+    uint32_t ind = blockIdx.x;
+    if (ind >= p_len) return; // whole workgroup
+    float2 x[E], y[E];
+    {
+        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * pitch);
+#pragma unroll
+        for (int sl = 0; sl < E; ++sl) x[sl] = in[tid + T * sl];
+    }
+    __syncthreads(); // target spectrum in place
+    while (true) {
+        if constexpr (WIN) {
+#pragma unroll
+            for (int sl = 0; sl < E; ++sl) x[sl] = make_float2(x[sl].x * wv[sl].x, x[sl].y * wv[sl].y);
+        }
+        const uint32_t nxt = ind + gridDim.x;
+        const bool more = nxt < p_len;
+        {
+            const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : ind) * pitch);
+#pragma unroll
+            for (int sl = 0; sl < E; ++sl) y[sl] = in[tid + T * sl];
+        }
+#define SOTS_WG_PASS(R, NS, OFF)                                              \
+    wg_pass<M, R, NS, T>(x, lds, tw, TWR ? &twr[OFF] : nullptr, tid);         \
+    __syncthreads();
+#define SOTS_WG_NEXT()                                                        \
+    _Pragma("unroll") for (int sl = 0; sl < E; ++sl) x[sl] = lds[lds_pad(tid + T * sl)]; \
+    __syncthreads();
+        if constexpr (M == 1024) {
+            SOTS_WG_PASS(8, 1, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 8, 0) SOTS_WG_NEXT() SOTS_WG_PASS(4, 64, 7) SOTS_WG_NEXT() SOTS_WG_PASS(4, 256, 13)
+        } else if constexpr (M == 2048) {
+            SOTS_WG_PASS(8, 1, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 8, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 64, 7) SOTS_WG_NEXT() SOTS_WG_PASS(4, 512, 14)
+        } else {
+            SOTS_WG_PASS(8, 1, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 8, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 64, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 512, 0)
+        }
+#undef SOTS_WG_PASS
+#undef SOTS_WG_NEXT
+        // Z is in LDS in natural order.  Split and error for k = tid + T q (and its mirror M - k)
+        const float2 zh = lds[lds_pad(M / 2)];
+        const float2 x_half = make_float2(zh.x, -zh.y); // bin M/2
+        float acc = 0.0f;
+        float2 *__restrict__ row = MODE == 0 ? reinterpret_cast<float2 *>(spectrum + (size_t)ind * (N + 8)) : nullptr;
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+            const int k = tid + T * q;
+            float2 xa, xb;
+            split_pair(lds[lds_pad(k)], lds[lds_pad((M - k) & (M - 1))], w_split[q], xa, xb);
+            if constexpr (MODE == 0) {
+                row[k] = xa;
+                row[M - k] = xb; // k = 0 lands on the Nyquist bin M
+            } else {
+                if (k == 0) xb = x_half; // the fitness skips the Nyquist bin and needs bin M/2
+                acc += bin_error(xa, tgt_s[k], inv_n, inv_wf);
+                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], inv_n, inv_wf);
+            }
+        }
+        if constexpr (MODE == 0) {
+            if (tid == 0) row[M / 2] = x_half;
+        } else {
+            acc = wave_sum(acc);
+            if ((tid & (kWave - 1)) == 0) red[tid / kWave] = acc;
+        }
+        __syncthreads(); // Z consumed (next row may overwrite it); wavefront sums in place
+        if constexpr (MODE == 1) {
+            if (tid == 0) {
+                float total = red[0];
+#pragma unroll
+                for (int w = 1; w < W; ++w) total += red[w];
+                fitness[ind] = total;
+            }
+        }
+        if (!more) break;
+        for (int sl = 0; sl < E; ++sl) x[sl] = y[sl];
+        ind = nxt;
+    }
+}
+
+// fitnessPopulation on materialised spectrum rows for N >= 2048: the bin -> thread map and the
+// summation order of k_fft_wg<.., 1>
+template <int LOG2N>
+__global__ __launch_bounds__(wg_threads<LOG2N>()) void k_fitness_wg(const float *__restrict__ spectrum,
+                                                                    const float *__restrict__ target,
+                                                                    float *__restrict__ fitness, uint32_t p_len,
+                                                                    float inv_n, float inv_wf)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, T = wg_threads<LOG2N>(), E = M / T, W = T / kWave;
+    __shared__ float red[W];
+    const int tid = threadIdx.x;
+    for (uint32_t ind = blockIdx.x; ind < p_len; ind += gridDim.x) {
+        const float2 *__restrict__ row = reinterpret_cast<const float2 *>(spectrum + (size_t)ind * (N + 8));
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < E / 2; ++q) {
+            const int k = tid + T * q;
+            const int kb = k == 0 ? M / 2 : M - k;
+            acc += bin_error(row[k], target[k], inv_n, inv_wf);
+            acc += bin_error(row[kb], target[kb], inv_n, inv_wf);
+        }
+        acc = wave_sum(acc);
+        if ((tid & (kWave - 1)) == 0) red[tid / kWave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            float total = red[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) total += red[w];
+            fitness[ind] = total;
+        }
+        __syncthreads();
+    }
+}
+
 #pragma clang fp contract(off)
 
 // ------------------------------------------------------------------------------------
@@ -1442,10 +1646,35 @@ static uint32_t resident_grid(K kernel, int threads, uint32_t items, uint32_t nu
     return (uint32_t)(items < cap ? items : cap);
 }
 
+// N >= kWgFrom uses the workgroup-per-row kernels (k_fft_wg, k_fitness_wg)
+static uint32_t wg_from()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("SOTS_FFT_WG_FROM"); // log2 of the first row length on the workgroup kernels (A/B)
+        const int x = e ? atoi(e) : 11;
+        return (uint32_t)(x < 11 ? 11 : x);
+    }();
+    return v;
+}
+
+#define SOTS_DISPATCH_WG(log2n, CALL)     \
+    switch (log2n) {                      \
+    case 11: { CALL(11); break; }         \
+    case 12: { CALL(12); break; }         \
+    case 13: { CALL(13); break; }         \
+    default: return hipErrorInvalidValue; \
+    }
+
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus)
 {
-    static int occ[16] = {0};
+    static int occ[16] = {0}, occ_wg[16] = {0};
+    if (log2n >= wg_from()) {
+#define CALL(L) k_fft_wg<L, 0, false><<<resident_grid(k_fft_wg<L, 0, false>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
+        SOTS_DISPATCH_WG(log2n, CALL)
+#undef CALL
+        return hipGetLastError();
+    }
 #define CALL(L) k_fft<L, 0, false><<<resident_grid(k_fft<L, 0, false>, kWave, p, num_cus, &occ[L]), kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
@@ -1455,7 +1684,13 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus)
 {
-    static int occ[16] = {0};
+    static int occ[16] = {0}, occ_wg[16] = {0};
+    if (log2n >= wg_from()) {
+#define CALL(L) k_fitness_wg<L><<<resident_grid(k_fitness_wg<L>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
+        SOTS_DISPATCH_WG(log2n, CALL)
+#undef CALL
+        return hipGetLastError();
+    }
 #define CALL(L) k_fitness<L><<<resident_grid(k_fitness<L>, kWave, p, num_cus, &occ[L]), kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
     SOTS_DISPATCH_LOG2N(log2n, CALL)
 #undef CALL
@@ -1466,7 +1701,19 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
                               float inv_n, float inv_wf, uint32_t num_cus)
 {
-    static int occ_w[16] = {0}, occ_n[16] = {0};
+    static int occ_w[16] = {0}, occ_n[16] = {0}, occ_wgw[16] = {0}, occ_wgn[16] = {0};
+    if (log2n >= wg_from()) {
+        if (window) {
+#define CALL(L) k_fft_wg<L, 1, true><<<resident_grid(k_fft_wg<L, 1, true>, wg_threads<L>(), p, num_cus, &occ_wgw[L]), wg_threads<L>(), 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+            SOTS_DISPATCH_WG(log2n, CALL)
+#undef CALL
+        } else {
+#define CALL(L) k_fft_wg<L, 1, false><<<resident_grid(k_fft_wg<L, 1, false>, wg_threads<L>(), p, num_cus, &occ_wgn[L]), wg_threads<L>(), 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
+            SOTS_DISPATCH_WG(log2n, CALL)
+#undef CALL
+        }
+        return hipGetLastError();
+    }
     if (window) {
 #define CALL(L) k_fft<L, 1, true><<<resident_grid(k_fft<L, 1, true>, kWave, p, num_cus, &occ_w[L]), kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
         SOTS_DISPATCH_LOG2N(log2n, CALL)
@@ -1479,8 +1726,6 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
     return hipGetLastError();
 }
 
-// Tile size and count of the rank-merge sort for a padded length, or tiles == 1 when one LDS
-// tile holds everything.  tiles > kSortMaxTiles falls back to global bitonic steps.
 constexpr uint32_t kSortMaxTiles = 256;
 
 static void sort_plan(uint32_t n_pad, uint32_t &tile, uint32_t &tiles)

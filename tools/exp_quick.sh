@@ -1,13 +1,7 @@
 set -e
-for m in 1 0; do
-echo "== parity SOTS_SYNTH_CUT=$m"; SOTS_SYNTH_CUT=$m timeout -k 10 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-done
+echo "== parity"; timeout -k 10 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 run() { echo "== $*"; timeout -k 10 300 python bench.py --steps 60 --warmup 6 --no-cpu-baseline "$@" 2>/dev/null > /tmp/b.log; python tools/show_bench.py /tmp/b.log; }
-for m in 1 0; do
-export SOTS_SYNTH_CUT=$m; echo "#### SOTS_SYNTH_CUT=$m"
-run --parents 4096 --offspring 12288
-run --parents 8192 --offspring 24576
-run --synth 3op_series --log2n 11 --parents 8192 --offspring 24576
+run
+run --synth 3op_series --log2n 11
 run --synth 4op_series --log2n 12 --parents 8192 --offspring 24576
-run --synth 4op_series --log2n 12 --parents 4096 --offspring 12288
-done
+run --log2n 13 --parents 4096 --offspring 12288
