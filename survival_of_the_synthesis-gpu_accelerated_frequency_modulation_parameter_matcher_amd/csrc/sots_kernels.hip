@@ -684,66 +684,38 @@ __device__ __forceinline__ void lds_reload(float2 (&x)[M / kWave], const float2 
 template <int M, int R>
 __device__ __forceinline__ void fft_first_pass(const float4 (&q)[M / kWave / 2], float2 *__restrict__ lds, int lane)
 {
-    constexpr int E = M / kWave, B = E / R;
-    static_assert(E % R == 0 && (B == 1 || B % 2 == 0), "unsupported first-pass shape");
-    if constexpr (B == 1) {
-        float2 v[R];
+    constexpr int E = M / kWave;
+    static_assert(E == R, "one first-pass butterfly per lane (N = 512: radix 4, N = 1024: radix 8)");
+    float2 v[R];
 #pragma unroll
-        for (int h = 0; h < R / 2; ++h) {
-            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[h].x), __float_as_uint(q[h].z), false, false);
-            const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[h].y), __float_as_uint(q[h].w), false, false);
-            v[2 * h] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
-            v[2 * h + 1] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
-        }
-        Dft<R>::run(v);
-        const int j = 2 * (lane & 31) + (lane >> 5);
-#pragma unroll
-        for (int t = 0; t < R; ++t) lds[lds_pad(j * R + t)] = v[t];
-    } else {
-#pragma unroll
-        for (int bb = 0; bb < B; bb += 2) {
-            float2 v0[R], v1[R];
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                const int h = (t * B + bb) / 2;
-                v0[t] = make_float2(q[h].x, q[h].y);
-                v1[t] = make_float2(q[h].z, q[h].w);
-            }
-            Dft<R>::run(v0);
-            Dft<R>::run(v1);
-            const int j = 2 * lane + kWave * bb;
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                lds[lds_pad(j * R + t)] = v0[t];
-                lds[lds_pad((j + 1) * R + t)] = v1[t];
-            }
-        }
+    for (int h = 0; h < R / 2; ++h) {
+        const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[h].x), __float_as_uint(q[h].z), false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[h].y), __float_as_uint(q[h].w), false, false);
+        v[2 * h] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+        v[2 * h + 1] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
     }
+    Dft<R>::run(v);
+    const int j = 2 * (lane & 31) + (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < R; ++t) lds[lds_pad(j * R + t)] = v[t];
 }
 
-// All passes for M complex points, starting from the row as loaded; leaves Z in natural
-// order in LDS (padded indexing).
-// Number of per-lane pass twiddles (all passes after the first) and whether the kernels keep
-// them in registers: yes up to M = 1024; beyond that they would not fit next to the data.
-template <int M> constexpr int tw_count() { return M == 256 ? 9 : M == 512 ? 14 : M == 1024 ? 38 : 1; }
-template <int M> constexpr bool tw_in_regs() { return M <= 1024; }
+// All passes for M complex points (N = 512: 4.4.4.4, N = 1024: 8.8.8), starting from the row as
+// loaded; the last pass stays in registers: x[s] = Z[lane + 64 s].  The per-lane pass twiddles
+// (all passes after the first) are loop-invariant and live in registers.
+template <int M> constexpr int tw_count() { return M == 256 ? 9 : 14; }
 
 template <int M>
 __device__ __forceinline__ void preload_twiddles(float2 (&twr)[tw_count<M>()], const float2 *__restrict__ tw, int lane)
 {
+    static_assert(M == 256 || M == 512, "wavefront-per-row FFT is for N <= 1024");
     if constexpr (M == 256) {
         load_pass_twiddles<M, 4, 4>(&twr[0], tw, lane);
         load_pass_twiddles<M, 4, 16>(&twr[3], tw, lane);
         load_pass_twiddles<M, 4, 64>(&twr[6], tw, lane);
-    } else if constexpr (M == 512) {
+    } else {
         load_pass_twiddles<M, 8, 8>(&twr[0], tw, lane);
         load_pass_twiddles<M, 8, 64>(&twr[7], tw, lane);
-    } else if constexpr (M == 1024) {
-        load_pass_twiddles<M, 8, 8>(&twr[0], tw, lane);
-        load_pass_twiddles<M, 4, 64>(&twr[14], tw, lane);
-        load_pass_twiddles<M, 4, 256>(&twr[26], tw, lane);
-    } else {
-        twr[0] = make_float2(0.f, 0.f);
     }
 }
 
@@ -756,24 +728,17 @@ __device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], fl
 #define SOTS_FIRST(R)                        \
     fft_first_pass<M, R>(q, lds, lane);      \
     SOTS_SYNC();
-#define SOTS_PASS(R, NS, OFF)                                                        \
-    fft_pass<M, R, NS>(x, lds, tw, tw_in_regs<M>() ? &twr[OFF] : nullptr, lane);     \
+#define SOTS_PASS(R, NS, OFF)                             \
+    fft_pass<M, R, NS>(x, lds, tw, &twr[OFF], lane);      \
     SOTS_SYNC();
 #define SOTS_NEXT()                          \
     lds_reload<M>(x, lds, lane);             \
     SOTS_SYNC();
-#define SOTS_LAST(R, NS, OFF) fft_pass<M, R, NS, true>(x, lds, tw, tw_in_regs<M>() ? &twr[OFF] : nullptr, lane);
+#define SOTS_LAST(R, NS, OFF) fft_pass<M, R, NS, true>(x, lds, tw, &twr[OFF], lane);
     if constexpr (M == 256) {
         SOTS_FIRST(4) SOTS_NEXT() SOTS_PASS(4, 4, 0) SOTS_NEXT() SOTS_PASS(4, 16, 3) SOTS_NEXT() SOTS_LAST(4, 64, 6)
-    } else if constexpr (M == 512) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_LAST(8, 64, 7)
-    } else if constexpr (M == 1024) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(4, 64, 14) SOTS_NEXT() SOTS_LAST(4, 256, 26)
-    } else if constexpr (M == 2048) {
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_LAST(4, 512, 0)
     } else {
-        static_assert(M == 4096, "unsupported FFT length");
-        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_PASS(8, 64, 0) SOTS_NEXT() SOTS_PASS(8, 512, 0) // 64 registers of Z per lane would spill: the split reads Z from LDS
+        SOTS_FIRST(8) SOTS_NEXT() SOTS_PASS(8, 8, 0) SOTS_NEXT() SOTS_LAST(8, 64, 7)
     }
 #undef SOTS_SYNC
 #undef SOTS_FIRST
@@ -793,8 +758,6 @@ __device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], fl
 // the LDS crossbar, no LDS memory and no bank conflicts (this replaces a write of the whole
 // transform to LDS and two reads of it).  Lane 0 pairs with itself one slot further:
 // Z[M - 64 q] = its own slot E-q, and Z[M] = Z[0] for q = 0.
-template <int M> constexpr bool z_in_regs() { return M <= 2048; }
-
 template <int M>
 __device__ __forceinline__ float2 split_partner(const float2 (&z)[M / kWave], int q, int lane, int partner_addr)
 {
@@ -852,9 +815,9 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // MODE 0: write spectrum rows; MODE 1: accumulate the fitness directly
-// WIN: multiply by the fp32 window while loading (the generation loop then skips both the
-// window pass and any window work in the synthesis kernel; the product is the same single
-// fp32 rounding either way).
+// WIN: multiply by the fp32 window while loading (the generation loop then skips the window
+// pass; the product is the same single fp32 rounding either way).
+// Rows of N <= 1024 only (longer rows: k_fft_wg below).
 template <int LOG2N, int MODE, bool WIN>
 __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
@@ -862,6 +825,7 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
                                                uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave, H = E / 2;
+    static_assert(LOG2N == 9 || LOG2N == 10, "wavefront-per-row FFT is for N <= 1024");
     __shared__ float2 lds[M + M / 8 + 1];
     const int lane = threadIdx.x;
     const int partner_addr = ((kWave - lane) & (kWave - 1)) * 4; // ds_bpermute byte address of lane 64-l
@@ -875,73 +839,49 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     for (int q = 0; q < H; ++q) w_split[q] = tw[lane + kWave * q];
     // the target spectrum sits in LDS (2N bytes): eight registers fewer than holding this lane's
     // bins, which is what keeps N = 1024 at three wavefronts per SIMD with two rows in flight
-    // (for N >= 4096 the LDS copy would cost occupancy instead: those keep their bins in registers)
-    constexpr bool TGT_LDS = MODE == 1 && LOG2N <= 11;
-    __shared__ float tgt_s[TGT_LDS ? M + 1 : 1];
-    float tgt_a[MODE == 1 && !TGT_LDS ? H : 1], tgt_b[MODE == 1 && !TGT_LDS ? H : 1];
-    if constexpr (TGT_LDS) {
+    __shared__ float tgt_s[MODE == 1 ? M + 1 : 1];
+    if constexpr (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < E; ++q) tgt_s[lane + kWave * q] = target[lane + kWave * q];
         __syncthreads();
-    } else if constexpr (MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < H; ++q) {
-            const int k = lane + kWave * q;
-            tgt_a[q] = target[k];
-            tgt_b[q] = target[k == 0 ? M / 2 : M - k];
-        }
     }
 
     // rows are read 16 bytes per lane: pair index lane + 64 h holds complex points 2(lane+64h), +1
     constexpr int Q = E / 2;
-    // N = 8192 holds 128 registers of row per lane: no room for a prefetched row or the window
-    constexpr bool LEAN = LOG2N >= 13;
-    float4 wv[WIN && !LEAN ? Q : 1];
-    if constexpr (WIN && !LEAN) {
+    float4 wv[WIN ? Q : 1];
+    if constexpr (WIN) {
 #pragma unroll
         for (int h = 0; h < Q; ++h) wv[h] = reinterpret_cast<const float4 *>(window)[lane + kWave * h];
     }
     float2 twr[tw_count<M>()];
     preload_twiddles<M>(twr, tw, lane);
-    // Row buffers rotate (no copies): DEPTH rows are in flight beside the one being transformed.
-    // Short rows (N <= 1024) use DEPTH = 2 - a row's transform is shorter than the loaded memory
-    // latency and the registers are there (168 = three wavefronts per SIMD); N = 8192 has no
-    // register left for any.
-    constexpr int DEPTH = LEAN ? 0 : LOG2N <= 10 ? 2 : 1;
+    // Three row buffers rotate (no copies): two rows are in flight beside the one being
+    // transformed - a row's transform is shorter than the loaded memory latency, and the registers
+    // are there (168 = three wavefronts per SIMD).
     auto request = [&](float4 (&dst)[Q], uint32_t r) { // rows past the end re-read the last valid one
         const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(r < p_len ? r : ind) * pitch);
 #pragma unroll
         for (int h = 0; h < Q; ++h) dst[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
     };
-    // transforms the row in `cur` (individual `ind`) after requesting row ind + (DEPTH) * grid into `fill`
+    // transforms the row in `cur` (individual `ind`) after requesting row ind + 2 grid into `fill`
     auto process = [&](float4 (&cur)[Q], float4 (&fill)[Q]) {
         if constexpr (WIN) {
 #pragma unroll
-            for (int h = 0; h < Q; ++h) {
-                const float4 w = LEAN ? reinterpret_cast<const float4 *>(window)[lane + kWave * h] : wv[h];
-                cur[h] = make_float4(cur[h].x * w.x, cur[h].y * w.y, cur[h].z * w.z, cur[h].w * w.w);
-            }
+            for (int h = 0; h < Q; ++h)
+                cur[h] = make_float4(cur[h].x * wv[h].x, cur[h].y * wv[h].y, cur[h].z * wv[h].z, cur[h].w * wv[h].w);
         }
-        if constexpr (DEPTH > 0) request(fill, ind + DEPTH * gridDim.x);
-        float2 z[E];
+        request(fill, ind + 2 * gridDim.x);
+        float2 z[E]; // z[s] = Z[lane + 64 s]
         fft_forward<M>(cur, lds, tw, twr, lane, z);
-        // z_in_regs: z[s] = Z[lane + 64 s]; otherwise Z is in LDS in natural order (padded indexing).
-        // Operands of the split for k = lane + 64 q:
-        auto z_k = [&](int q) { return z_in_regs<M>() ? z[q] : lds[lds_pad(lane + kWave * q)]; };
-        auto z_mk = [&](int q) {
-            if constexpr (z_in_regs<M>()) return split_partner<M>(z, q, lane, partner_addr);
-            else return lds[lds_pad((M - (lane + kWave * q)) & (M - 1))];
-        };
         // bin M/2 = conj Z[M/2]; Z[M/2] = Z[0 + 64 (E/2)] is lane 0's slot E/2, and only lane 0 (k = 0) uses it
-        const float2 zh = z_in_regs<M>() ? z[E / 2] : lds[lds_pad(M / 2)];
-        const float2 x_half = make_float2(zh.x, -zh.y);
+        const float2 x_half = make_float2(z[E / 2].x, -z[E / 2].y);
         if constexpr (MODE == 0) {
             float2 *__restrict__ row = reinterpret_cast<float2 *>(spectrum + (size_t)ind * (N + 8));
 #pragma unroll
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
                 float2 xa, xb;
-                split_pair(z_k(q), z_mk(q), w_split[q], xa, xb);
+                split_pair(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa, xb);
                 row[k] = xa;
                 row[M - k] = xb; // k = 0 lands on the Nyquist bin M
             }
@@ -952,10 +892,10 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
                 float2 xa, xb;
-                split_pair(z_k(q), z_mk(q), w_split[q], xa, xb);
+                split_pair(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa, xb);
                 if (k == 0) xb = x_half; // the fitness skips the Nyquist bin and needs bin M/2
-                acc += bin_error(xa, TGT_LDS ? tgt_s[k] : tgt_a[q], inv_n, inv_wf);
-                acc += bin_error(xb, TGT_LDS ? tgt_s[k == 0 ? M / 2 : M - k] : tgt_b[q], inv_n, inv_wf);
+                acc += bin_error(xa, tgt_s[k], inv_n, inv_wf);
+                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], inv_n, inv_wf);
             }
             acc = wave_sum(acc);
             if (lane == 0) fitness[ind] = acc;
@@ -964,36 +904,14 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
         __syncthreads(); // single-wavefront workgroup: orders this row's LDS reads before the next row's writes
         return ind < p_len;
     };
-    if constexpr (DEPTH == 0) {
-        float4 b0[Q];
-        do request(b0, ind);
-        while (process(b0, b0));
-    } else if constexpr (DEPTH == 1 && LOG2N >= 12) {
-        // one copy of the loop body and a register copy per row: the two-body rotation below
-        // needs more registers than N = 4096 has
-        float4 b0[Q], b1[Q];
-        request(b0, ind);
-        while (process(b0, b1)) {
-#pragma unroll
-            for (int h = 0; h < Q; ++h) b0[h] = b1[h];
-        }
-    } else if constexpr (DEPTH == 1) {
-        float4 b0[Q], b1[Q];
-        request(b0, ind);
-        while (true) {
-            if (!process(b0, b1)) break;
-            if (!process(b1, b0)) break;
-        }
-    } else {
-        float4 b0[Q], b1[Q], b2[Q];
-        request(b0, ind);
-        asm volatile("" ::: "memory"); // keep the two requests in this order (the loop's waits count on it)
-        request(b1, ind + gridDim.x);
-        while (true) {
-            if (!process(b0, b2)) break;
-            if (!process(b1, b0)) break;
-            if (!process(b2, b1)) break;
-        }
+    float4 b0[Q], b1[Q], b2[Q];
+    request(b0, ind);
+    asm volatile("" ::: "memory"); // keep the two requests in this order (the loop's waits count on it)
+    request(b1, ind + gridDim.x);
+    while (true) {
+        if (!process(b0, b2)) break;
+        if (!process(b1, b0)) break;
+        if (!process(b2, b1)) break;
     }
 }
 
@@ -1620,16 +1538,6 @@ hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint
     return hipGetLastError();
 }
 
-#define SOTS_DISPATCH_LOG2N(log2n, CALL)  \
-    switch (log2n) {                      \
-    case 9: { CALL(9); break; }           \
-    case 10: { CALL(10); break; }         \
-    case 11: { CALL(11); break; }         \
-    case 12: { CALL(12); break; }         \
-    case 13: { CALL(13); break; }         \
-    default: return hipErrorInvalidValue; \
-    }
-
 // Grid of a grid-stride kernel whose items all cost the same: exactly as many workgroups as
 // are resident at once (occupancy query, cached per kernel).  A larger grid runs in rounds
 // and the last, partly filled round costs as much as a full one (measured: 4096 one-wave
@@ -1646,16 +1554,15 @@ static uint32_t resident_grid(K kernel, int threads, uint32_t items, uint32_t nu
     return (uint32_t)(items < cap ? items : cap);
 }
 
-// N >= kWgFrom uses the workgroup-per-row kernels (k_fft_wg, k_fitness_wg)
-static uint32_t wg_from()
-{
-    static const uint32_t v = [] {
-        const char *e = getenv("SOTS_FFT_WG_FROM"); // log2 of the first row length on the workgroup kernels (A/B)
-        const int x = e ? atoi(e) : 11;
-        return (uint32_t)(x < 11 ? 11 : x);
-    }();
-    return v;
-}
+// N >= 2048 runs on the workgroup-per-row kernels (k_fft_wg, k_fitness_wg), shorter rows on the
+// wavefront-per-row ones
+static constexpr uint32_t wg_from() { return 11; }
+#define SOTS_DISPATCH_WAVE(log2n, CALL)   \
+    switch (log2n) {                      \
+    case 9: { CALL(9); break; }           \
+    case 10: { CALL(10); break; }         \
+    default: return hipErrorInvalidValue; \
+    }
 
 #define SOTS_DISPATCH_WG(log2n, CALL)     \
     switch (log2n) {                      \
@@ -1676,7 +1583,7 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
         return hipGetLastError();
     }
 #define CALL(L) k_fft<L, 0, false><<<resident_grid(k_fft<L, 0, false>, kWave, p, num_cus, &occ[L]), kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
-    SOTS_DISPATCH_LOG2N(log2n, CALL)
+    SOTS_DISPATCH_WAVE(log2n, CALL)
 #undef CALL
     return hipGetLastError();
 }
@@ -1692,7 +1599,7 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
         return hipGetLastError();
     }
 #define CALL(L) k_fitness<L><<<resident_grid(k_fitness<L>, kWave, p, num_cus, &occ[L]), kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
-    SOTS_DISPATCH_LOG2N(log2n, CALL)
+    SOTS_DISPATCH_WAVE(log2n, CALL)
 #undef CALL
     return hipGetLastError();
 }
@@ -1716,12 +1623,12 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
     }
     if (window) {
 #define CALL(L) k_fft<L, 1, true><<<resident_grid(k_fft<L, 1, true>, kWave, p, num_cus, &occ_w[L]), kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
-        SOTS_DISPATCH_LOG2N(log2n, CALL)
+        SOTS_DISPATCH_WAVE(log2n, CALL)
 #undef CALL
         return hipGetLastError();
     }
 #define CALL(L) k_fft<L, 1, false><<<resident_grid(k_fft<L, 1, false>, kWave, p, num_cus, &occ_n[L]), kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
-    SOTS_DISPATCH_LOG2N(log2n, CALL)
+    SOTS_DISPATCH_WAVE(log2n, CALL)
 #undef CALL
     return hipGetLastError();
 }
