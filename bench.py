@@ -29,6 +29,13 @@ sys.path.insert(0, ROOT)
 PKG = "survival_of_the_synthesis-gpu_accelerated_frequency_modulation_parameter_matcher_amd"
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+# shares of the stage-separated B_alg = 24N+16 bytes per candidate that fall to each fused kernel
+B_ALG_SHARE = {
+    "recombine+mutate": lambda n, d: 16 * d,
+    "synthesise": lambda n, d: 4 * n,                      # synth write
+    "window+FFT+fitness": lambda n, d: 20 * n + 16,        # window r+w 8N, FFT read 4N + write 8(N/2+1), fitness read 8(N/2+1)
+    "sortPopulation": lambda n, d: 16 + 8 * (2 * d + 1),
+}
 # voice -> (synth kind name, paramMaxs, target parameters in the unit cube)
 VOICES = {
     "2op": ([3520.0, 8.0, 3520.0, 1.0], [1450.0 / 3520.0, 3.0 / 8.0, 200.0 / 3520.0, 1.0]),
@@ -51,7 +58,7 @@ def make_target(pkg, voice, log2n, device):
     return audio
 
 
-def cpu_baseline(voice, log2n, target_audio, budget_s=12.0):
+def cpu_baseline(voice, log2n, target_audio, budget_s=10.0):
     """The CPU oracle (oracle/sots_oracle.c, a single-threaded port of the reference's
     Evolutionary_Strategy_CPU path) timed on this host on a bounded sample of the workload."""
     from oracle import oracle as O
@@ -70,9 +77,27 @@ def cpu_baseline(voice, log2n, target_audio, budget_s=12.0):
         ref.generation()
     dt = time.perf_counter() - t0
     p = parents + offspring
-    return {"value": p * gens / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
-            "sample": f"pop={p} x {gens} generations, {voice} FM, N={1 << log2n}, fp64 built-in FFT "
-                      f"(FFTW unavailable), {dt:.1f} s on 1 core"}
+    out = {"value": p * gens / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
+           "sample": f"pop={p} x {gens} generations, {voice} FM, N={1 << log2n}, fp64 built-in FFT "
+                     f"(FFTW unavailable), {dt:.1f} s on 1 core"}
+    # the reference's CPU path is single-threaded (the faithful baseline above); additionally
+    # the evaluation loop (synthesis + FFT + fitness, independent per individual) over all host cores
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    if cores > 1:
+        O.set_threads(cores)
+        gens_mt = max(2, min(5000, int(0.5 * budget_s / max(one / cores, 1e-6))))
+        t0 = time.perf_counter()
+        for _ in range(gens_mt):
+            ref.generation()
+        dt_mt = time.perf_counter() - t0
+        O.set_threads(1)
+        out["all_cores"] = {"value": p * gens_mt / dt_mt, "unit": "candidates/s", "cores": cores,
+                            "sample": f"same workload, evaluation loop under OpenMP on {cores} threads "
+                                      f"(variation and sort stay serial), {gens_mt} generations in {dt_mt:.1f} s"}
+    return out
 
 
 def main():
@@ -225,6 +250,11 @@ def main():
                        "parallelism": f"island x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "basis": "bytes this FUSED kernel has to move (DESIGN.md 3.2), not its share of SURVEY 8(d)'s "
+                                  "stage-separated B_alg = 24N+16; that basis is given in achieved_b_alg_share / frac_b_alg_share "
+                                  "and is an effective bandwidth that exceeds 1 once stages are fused",
+                         "achieved_b_alg_share": B_ALG_SHARE[dom](N, es.D) * P / (dk["avg_us"] * 1e-6) / 1e9,
+                         "frac_b_alg_share": B_ALG_SHARE[dom](N, es.D) * P / (dk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" if traffic else None,
                          "avg_kernel_us": dk["avg_us"],
                          "alg_bytes_per_launch": dk["alg_bytes_per_candidate"] * P},

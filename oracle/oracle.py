@@ -119,6 +119,11 @@ def pad_params(p):
     return out
 
 
+def set_threads(n):
+    """Threads of OracleES.evaluate()/generation() (all-cores CPU baseline only; default 1)."""
+    lib().sots_or_set_threads(int(n))
+
+
 def synth(kind, values, pmin, pmax, n, table=None):
     table = wavetable() if table is None else table
     out = np.zeros(n, np.float32)

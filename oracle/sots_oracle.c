@@ -259,10 +259,9 @@ static rfft_plan *plan_for(uint32_t n)
 }
 
 /* bins 0..n/2 of the forward DFT of x[0..n-1] */
-static void rfft_exec(rfft_plan *pl, const double *x, double *re, double *im)
+static void rfft_exec_ws(const rfft_plan *pl, const double *x, double *re, double *im, double *zr, double *zi)
 {
-    const uint32_t n = pl->n, m = n / 2;
-    double *zr = pl->zr, *zi = pl->zi;
+    const uint32_t n = pl->n, m = n / 2; /* zr, zi: caller's work space, n/2 doubles each */
     for (uint32_t i = 0; i < m; ++i) {
         const uint32_t r = pl->rev[i];
         zr[r] = x[2 * i];
@@ -299,6 +298,11 @@ static void rfft_exec(rfft_plan *pl, const double *x, double *re, double *im)
     }
 }
 
+static void rfft_exec(rfft_plan *pl, const double *x, double *re, double *im)
+{
+    rfft_exec_ws(pl, x, re, im, pl->zr, pl->zi); /* the plan's own work space: single-threaded callers */
+}
+
 void sots_or_rfft(const float *audio, uint32_t n, const double *window, double *re, double *im)
 {
     rfft_plan *pl = plan_for(n);
@@ -330,10 +334,10 @@ void sots_or_spectrum(const float *audio, uint32_t n, const double *window, floa
     /* Evolutionary_Strategy.hpp:503-523 / 524-542 */
     rfft_plan *pl = plan_for(n);
     const uint32_t half = n / 2;
-    double *x = (double *)malloc(sizeof(double) * (size_t)(n + 2 * (half + 1)));
-    double *re = x + n, *im = re + half + 1;
+    double *x = (double *)malloc(sizeof(double) * (size_t)(n + 2 * (half + 1) + 2 * half));
+    double *re = x + n, *im = re + half + 1, *zr = im + half + 1, *zi = zr + half;
     for (uint32_t i = 0; i < n; ++i) x[i] = audio[i] * window[i];
-    rfft_exec(pl, x, re, im);
+    rfft_exec_ws(pl, x, re, im, zr, zi); /* private work space: callable from several threads once the plan exists */
     const float one_over_size = 1.0f / (float)n;               /* :296 */
     const float one_over_wf = 1.f / window_factor;              /* :317 */
     for (uint32_t k = 0; k < half; ++k) {
@@ -557,8 +561,18 @@ void sots_or_es_mutate(sots_or_es *es)
     sots_or_mutate(es->values, es->steps, es->p, es->d, es->cfg.seed, es->cfg.gid_base, es->generation);
 }
 
+/* Threads for sots_or_es_evaluate (bench.py's all-cores CPU baseline).  The default, 1, is the
+ * reference's behaviour: its CPU path has no threads anywhere.  Individuals are independent, so
+ * the results do not depend on the thread count. */
+static int g_eval_threads = 1;
+void sots_or_set_threads(int n) { g_eval_threads = n < 1 ? 1 : n; }
+
 void sots_or_es_evaluate(sots_or_es *es)
 {
+    (void)plan_for(es->n); /* create the shared plan before any thread needs it */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_eval_threads)
+#endif
     for (uint32_t i = 0; i < es->p; ++i) {
         float *a = es->audio + (size_t)i * es->n;
         float *m = es->mag + (size_t)i * es->half;

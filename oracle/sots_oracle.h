@@ -98,6 +98,7 @@ void sots_or_es_set_generation(sots_or_es *es, uint32_t generation);
 /* individual stages on the current state */
 void sots_or_es_recombine(sots_or_es *es);
 void sots_or_es_mutate(sots_or_es *es);
+void sots_or_set_threads(int n); /* threads of sots_or_es_evaluate; default 1 */
 void sots_or_es_evaluate(sots_or_es *es); /* synth + window + fft + fitness */
 void sots_or_es_sort(sots_or_es *es);
 void sots_or_es_generation(sots_or_es *es);
