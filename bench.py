@@ -60,7 +60,9 @@ def make_target(pkg, voice, log2n, device):
 
 def cpu_baseline(voice, log2n, target_audio, budget_s=10.0):
     """The CPU oracle (oracle/sots_oracle.c, a single-threaded port of the reference's
-    Evolutionary_Strategy_CPU path) timed on this host on a bounded sample of the workload."""
+    Evolutionary_Strategy_CPU path) timed on this host on a bounded sample of the workload.
+    Both legs stop on the clock, so the sample size adapts to the host."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP threads sleep instead of spinning
     from oracle import oracle as O
     parents, offspring = 512, 1536
     kind = {"2op": O.SYNTH_2OP, "3op_series": O.SYNTH_3OP_SERIES, "4op_series": O.SYNTH_4OP_SERIES,
@@ -68,32 +70,35 @@ def cpu_baseline(voice, log2n, target_audio, budget_s=10.0):
     ref = O.OracleES(parents, offspring, kind, log2n, None, VOICES[voice][0], seed=0x5EED0001, recomb_block=32)
     ref.set_target_audio(target_audio)
     ref.init_population(0)
-    t0 = time.perf_counter()
-    ref.generation()
-    one = time.perf_counter() - t0
-    gens = max(2, min(5000, int(budget_s / max(one, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(gens):
-        ref.generation()
-    dt = time.perf_counter() - t0
     p = parents + offspring
+
+    def timed(budget):
+        ref.generation()  # warm
+        gens, t0 = 0, time.perf_counter()
+        while True:
+            ref.generation()
+            gens += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or gens >= 5000:
+                return gens, dt
+
+    gens, dt = timed(budget_s)
     out = {"value": p * gens / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
            "sample": f"pop={p} x {gens} generations, {voice} FM, N={1 << log2n}, fp64 built-in FFT "
                      f"(FFTW unavailable), {dt:.1f} s on 1 core"}
     # the reference's CPU path is single-threaded (the faithful baseline above); additionally
-    # the evaluation loop (synthesis + FFT + fitness, independent per individual) over all host cores
+    # the evaluation loop (synthesis + FFT + fitness, independent per individual) on the box's CPU share
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    cores = min(cores, 16)  # a one-GPU box owns 16 CPUs whatever the affinity mask says
     if cores > 1:
         O.set_threads(cores)
-        gens_mt = max(2, min(5000, int(0.5 * budget_s / max(one / cores, 1e-6))))
-        t0 = time.perf_counter()
-        for _ in range(gens_mt):
-            ref.generation()
-        dt_mt = time.perf_counter() - t0
-        O.set_threads(1)
+        try:
+            gens_mt, dt_mt = timed(0.5 * budget_s)
+        finally:
+            O.set_threads(1)
         out["all_cores"] = {"value": p * gens_mt / dt_mt, "unit": "candidates/s", "cores": cores,
                             "sample": f"same workload, evaluation loop under OpenMP on {cores} threads "
                                       f"(variation and sort stay serial), {gens_mt} generations in {dt_mt:.1f} s"}
