@@ -340,9 +340,9 @@ def test_audio_after_fused_loop_is_the_raw_synthesis(pkg, O, kind, log2n, parent
 
 
 def test_config2_trajectory_per_generation_parity(pkg, O):
-    """BASELINE config 2: P=1024 (256+768), 2-op, N=1024.  Each generation the oracle is
-    re-synchronised to the device's pre-generation state, runs the same generation, and both
-    results must agree stage by stage."""
+    """BASELINE config 2: P=1024 (256+768), 2-op, N=1024, 100 generations.  Each
+    generation the oracle is re-synchronised to the device's pre-generation state, runs the same
+    generation, and both results must agree stage by stage."""
     es, ref = make_pair(pkg, O, 256, 768, 0, 10)
     tgt, _ = target_audio(O, 0, es.N)
     es.set_target_audio(tgt)
@@ -350,7 +350,7 @@ def test_config2_trajectory_per_generation_parity(pkg, O):
     es.init_population(0)
     atol = fit_atol(O, tgt)
     best = []
-    for gen in range(20):
+    for gen in range(100):
         v, s, f = es.read_population()
         ref.write_population(v, s, f)
         ref.set_generation(gen)
@@ -371,7 +371,7 @@ def test_config2_trajectory_per_generation_parity(pkg, O):
         perm = O.sort_perm(gf)
         assert np.array_equal(sf, gf[perm]) and np.array_equal(sv, gv[perm]) and np.array_equal(ss, gs[perm])
         best.append(float(sf[0]))
-    assert es.generation == 20
+    assert es.generation == 100
     # (mu + lambda)-style selection on a re-evaluated population is not monotone, but the search
     # must make progress on this easy target
     assert min(best) < best[0]
