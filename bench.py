@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --share-gpu rehearses N > 1 on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank to cuda:0 (rehearsal only)")
-    ap.add_argument("--timing-every", type=int, default=8,
+    ap.add_argument("--timing-every", type=int, default=16,
                     help="record per-kernel HIP events on every k-th timed step only (0 = never)")
     args = ap.parse_args()
 
