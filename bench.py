@@ -203,6 +203,10 @@ def main():
         ms, cnt = es.stage_time_ms(stage)
         if cnt:
             kernels[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt), "alg_bytes_per_candidate": alg_bytes}
+    if "recombine+mutate" not in kernels and "synthesise" in kernels:
+        # large 4-gene populations: the synthesis kernel makes its own individuals
+        kernels["synthesise"]["alg_bytes_per_candidate"] += 16 * es.D
+        kernels["synthesise"]["includes"] = "recombine+mutate"
     fitness = es.read_fitness()
     best = float(fitness[0])
     # What crossing the boundary with HOST buffers would cost (never part of `value`): a blocking

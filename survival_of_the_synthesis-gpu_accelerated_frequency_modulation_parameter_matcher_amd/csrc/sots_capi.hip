@@ -578,7 +578,16 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
     if (int rc = bind_device(ctx)) return rc;
     for (uint32_t g = 0; g < n; ++g) {
         uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
-        {
+        // Large populations of 4-gene individuals make their individuals inside the synthesis kernel
+        // (one launch less, 151 vs 157 us per generation at P = 65536); with few wavefronts per CU or
+        // more genes the serial per-lane variation costs more than the launch it saves (measured).
+        static const int fuse_env = [] {
+            const char *e = getenv("SOTS_FUSE_VARIATION"); // 0 / 1 force it off / on (A/B profiling)
+            return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        }();
+        const bool fuse_variation = fuse_env >= 0 ? fuse_env == 1
+                                                  : (ctx->pd.d <= 4 && ctx->P >= 192u * (ctx->num_cus ? ctx->num_cus : 256u));
+        if (!fuse_variation) {
             StageScope t(ctx, SOTS_STAGE_FUSED_VARIATION);
             SOTS_HIP(ctx, launch_recombine_mutate(ctx->stream, ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst),
                                                   ctx->pd, ctx->mc, ctx->generation));
@@ -586,9 +595,12 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         ctx->rot = dst;
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH);
-            // raw synthesis: the window is applied by the FFT kernel as it loads the row
+            // raw synthesis (the window is applied by the FFT kernel as it loads the row); by default the
+            // kernel also makes its individuals: recombination + mutation from the sorted half
+            sots::Variation var = {ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst), ctx->pd, ctx->mc, ctx->generation};
             SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable,
-                                       ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
+                                       ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus,
+                                       fuse_variation ? &var : nullptr));
         }
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL);

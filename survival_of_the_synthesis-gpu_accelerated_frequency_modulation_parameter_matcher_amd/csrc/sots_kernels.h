@@ -35,6 +35,18 @@ struct PopDims {
     uint32_t seed_lo, seed_hi;
 };
 
+// Variation folded into the synthesis kernel (fused generation loop): when vin != nullptr every
+// lane first builds its individual - recombination source rows of the current half, mutation -
+// writes it to the other half and synthesises from it; with vin == nullptr the kernel reads
+// `values` as is.
+struct Variation {
+    const float *vin, *sin; // current half (sorted)
+    float *vout, *sout;     // other half
+    PopDims pd;
+    MutateConsts mc;
+    uint32_t generation;
+};
+
 // ---- variation ----
 hipError_t launch_init_population(hipStream_t st, float *values, float *steps, float *fitness,
                                   const PopDims &pd, uint32_t chunk);
@@ -52,7 +64,7 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 // would put every lane of a row-per-lane store on the same memory channel.
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
-                        uint32_t num_cus);
+                        uint32_t num_cus, const Variation *var = nullptr);
 hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n,
                          uint32_t pitch);
 // audio[P][pitch] -> spectrum[P][N+8]

@@ -318,7 +318,7 @@ template <int KIND, int SPLIT>
 __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__restrict__ values,
                                                                const float *__restrict__ wavetable,
                                                                float *__restrict__ audio, SynthParams sp,
-                                                               uint32_t p_len, uint32_t n, uint32_t pitch)
+                                                               uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
 {
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
     constexpr int U = kSynthUnroll;
@@ -351,12 +351,31 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
         const uint32_t ind = row0 + lane < p_len ? row0 + lane : p_len - 1u;
         const bool full = row0 + kWave <= p_len; // every row of the tile exists
         float p[D];
+        if (var.vin) {
+            // fused generation loop: this lane's individual is made here (k_recombine_mutate's
+            // arithmetic, gene by gene) and written to the other half by the wavefront that owns the row
+            const bool owner = !front && row0 + lane < p_len;
+#pragma unroll 1
+            for (int g = 0; g < D; ++g) {
+                const uint32_t src = recombine_source(ind, (uint32_t)g, var.pd);
+                float x = var.vin[src], st = var.sin[src];
+                mutate_gene(x, st, var.pd.gid_base + ind, (uint32_t)g, var.generation, var.pd, var.mc);
+                if (owner) {
+                    var.vout[(size_t)ind * D + g] = x;
+                    var.sout[(size_t)ind * D + g] = st;
+                }
+                p[g] = x;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < D; ++g) p[g] = values[(size_t)ind * D + g];
+        }
 #pragma unroll
         for (int g = 0; g < D; ++g) {
             // scaleParams: min + v*(max-min), ocl_program.cl:297; the triple voice scales all
             // three 2-op voices by entries 0..3, Evolutionary_Strategy.hpp:453-455
             const int sc = KIND == SOTS_SYNTH_TRIPLE_PAR ? (g & 3) : g;
-            p[g] = sp.pmin[sc] + values[(size_t)ind * D + g] * (sp.pmax[sc] - sp.pmin[sc]);
+            p[g] = sp.pmin[sc] + p[g] * (sp.pmax[sc] - sp.pmin[sc]);
         }
         // Operator 0 of chain j runs free at inc0[j]; operator s >= 1 advances by
         // c * (t_prev * mul[s][j] + off[s][j]); the output is gain[j] * (last operator's table value).
@@ -1498,8 +1517,10 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
-                        uint32_t num_cus)
+                        uint32_t num_cus, const Variation *variation)
 {
+    Variation var = {};
+    if (variation) var = *variation;
     const uint32_t n = 1u << log2n;
     const uint32_t cus = num_cus ? num_cus : 256;
     // The 128 KiB table allows one workgroup per CU, so the workgroup is sized to the CU's share
@@ -1516,14 +1537,14 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     const uint32_t threads = (cut ? 2 : 1) * waves * kWave, grid = grid_for(p, waves * kWave, cus);
 #define SOTS_SYNTH_CASE(K, S)                                                                            \
     case K:                                                                                              \
-        if (cut) k_synth<K, S><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);     \
-        else k_synth<K, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch);         \
+        if (cut) k_synth<K, S><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); \
+        else k_synth<K, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);     \
         break;
     switch (kind) {
         SOTS_SYNTH_CASE(SOTS_SYNTH_2OP, 1)
         SOTS_SYNTH_CASE(SOTS_SYNTH_3OP_SERIES, 2)
         SOTS_SYNTH_CASE(SOTS_SYNTH_4OP_SERIES, 2)
-    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); break;
     default: return hipErrorInvalidValue;
     }
 #undef SOTS_SYNTH_CASE
