@@ -21,7 +21,7 @@ out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (t
                   "MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)",
        "synthesise": round(nbytes(pick("k_synth"))),
        "window+FFT+fitness": round(nbytes(pick("k_fft"))),
-       "recombine+mutate": round(nbytes("k_recombine_mutate")),
+       "recombine+mutate": round(nbytes("k_recombine_mutate")) if "k_recombine_mutate" in d else None,
        "sortPopulation": round(sum(nbytes(k) for k in d if k.startswith("k_sort")))}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
