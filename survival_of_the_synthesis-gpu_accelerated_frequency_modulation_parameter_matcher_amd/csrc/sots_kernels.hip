@@ -1342,13 +1342,17 @@ constexpr uint32_t kRankLdsKeys = 8192; // LDS capacity in keys
 // sorted index and no tile needs a special case.  The tiles are staged by LDS-DMA (all pieces
 // in flight at once) and the GROUP x 4 binary searches of a thread advance together, one level
 // per trip, so a trip has GROUP x 4 independent LDS reads in flight instead of 4.
-template <uint32_t GROUP>
+// MERGE (large populations, first of two levels): the grid has one workgroup per tile, which ranks its
+// keys inside its OWN group of GROUP tiles only and writes them to their place in the group's
+// sorted run of GROUP * tile keys (merged[]); the second level then ranks runs instead of tiles.
+template <uint32_t GROUP, bool MERGE = false>
 __global__ __launch_bounds__(kRankThreads) void k_sort_rank_pairs(const uint64_t *__restrict__ keys,
                                                                   uint16_t *__restrict__ partial,
-                                                                  uint32_t n_pad, uint32_t tile)
+                                                                  uint32_t n_pad, uint32_t tile,
+                                                                  uint64_t *__restrict__ merged = nullptr)
 {
     __shared__ uint64_t s[kRankLdsKeys];
-    const uint32_t a = blockIdx.x, g = blockIdx.y;
+    const uint32_t a = blockIdx.x, g = MERGE ? blockIdx.x / GROUP : blockIdx.y;
     const uint64_t *__restrict__ kb = keys + (size_t)g * GROUP * tile;
     {
         typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -1383,7 +1387,11 @@ __global__ __launch_bounds__(kRankThreads) void k_sort_rank_pairs(const uint64_t
 #pragma unroll
             for (uint32_t bb = 0; bb < GROUP; ++bb) total += pos[bb][q] + ((s[bb * tile + pos[bb][q]] < x[q]) ? 1u : 0u);
             const uint32_t i = i0 + q * kRankThreads;
-            if (i < tile) out[i] = (uint16_t)total;
+            if constexpr (MERGE) {
+                if (i < tile) merged[(size_t)g * GROUP * tile + total] = x[q];
+            } else {
+                if (i < tile) out[i] = (uint16_t)total;
+            }
         }
     }
 }
@@ -1655,14 +1663,20 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
 }
 
 constexpr uint32_t kSortMaxTiles = 256;
+constexpr uint32_t kSortTwoLevelFrom = 131072; // padded population from which runs of 8 tiles are merged first
+
+// Plans: one LDS tile (n_pad <= 4096); tiles of 1024 + one rank level (up to 65536: 64 tiles);
+// tiles of 1024 merged into runs of 8192 + a rank level over the runs (two levels: the rank work is
+// quadratic in the number of sorted pieces, 128 tiles -> 16 runs at 131072); beyond 128 runs
+// (n_pad > 1M) global bitonic steps over tiles of 4096.
+constexpr uint32_t kSortMaxRuns = 128;         // 1 Mi keys; the counts of the run level take runs * n_pad * 2 bytes
+static bool sort_two_level(uint32_t n_pad) { return n_pad >= kSortTwoLevelFrom && n_pad / kRankLdsKeys <= kSortMaxRuns; }
 
 static void sort_plan(uint32_t n_pad, uint32_t &tile, uint32_t &tiles)
 {
-    if (n_pad <= kSortTile) {
-        tile = n_pad;
-    } else {
-        tile = n_pad <= 131072u ? 1024u : kSortTile;
-    }
+    if (n_pad <= kSortTile) tile = n_pad;
+    else if (n_pad <= 65536u || sort_two_level(n_pad)) tile = 1024u;
+    else tile = kSortTile;
     tiles = n_pad / tile;
 }
 
@@ -1676,14 +1690,23 @@ static uint32_t rank_group(uint32_t tile, uint32_t tiles)
     return group;
 }
 
-size_t sort_scratch_bytes(uint32_t p)
+// scratch layout: [partial counts (u16)] then, for two levels, [merged runs (u64, n_pad keys)]
+static size_t sort_partial_bytes(uint32_t n_pad)
 {
-    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
     uint32_t tile, tiles;
     sort_plan(n_pad, tile, tiles);
+    if (sort_two_level(n_pad)) return (size_t)(n_pad / kRankLdsKeys) * n_pad * sizeof(uint16_t);
     if (tiles <= 1 || tiles > kSortMaxTiles) return 16;
     const uint32_t group = rank_group(tile, tiles);
     return (size_t)(tiles / group) * n_pad * sizeof(uint16_t);
+}
+
+size_t sort_scratch_bytes(uint32_t p)
+{
+    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    size_t bytes = (sort_partial_bytes(n_pad) + 255) & ~(size_t)255;
+    if (sort_two_level(n_pad)) bytes += (size_t)n_pad * sizeof(uint64_t);
+    return bytes;
 }
 
 hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
@@ -1695,11 +1718,24 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
     sort_plan(n_pad, tile, tiles);
     uint32_t threads = tile / 2;
     threads = threads < 64 ? 64 : threads > (uint32_t)kSortThreads ? (uint32_t)kSortThreads : threads;
-    const bool rank_merge = tiles > 1 && tiles <= kSortMaxTiles;
+    const bool two_level = sort_two_level(n_pad);
+    const bool rank_merge = two_level || (tiles > 1 && tiles <= kSortMaxTiles);
     if (rank_merge && tile == 4 * kRunKeys)
         k_sort_tiles_1k<<<tiles, 256, 0, st>>>(fin, keys, p);
     else
         k_sort_tiles<<<tiles, threads, 0, st>>>(fin, keys, p, tile, rank_merge ? 0u : 1u);
+    if (two_level) {
+        uint16_t *partial = static_cast<uint16_t *>(scratch);
+        uint64_t *merged = reinterpret_cast<uint64_t *>(static_cast<char *>(scratch) +
+                                                        ((sort_partial_bytes(n_pad) + 255) & ~(size_t)255));
+        // level 1: groups of 8 tiles -> sorted runs of 8192 keys; level 2: every key against every run
+        k_sort_rank_pairs<kRankGroup, true><<<tiles, kRankThreads, 0, st>>>(keys, nullptr, n_pad, tile, merged);
+        const uint32_t runs = n_pad / kRankLdsKeys;
+        k_sort_rank_pairs<1><<<dim3(runs, runs), kRankThreads, 0, st>>>(merged, partial, n_pad, kRankLdsKeys);
+        k_sort_rank_scatter<<<n_pad / 64, kRankThreads, 0, st>>>(merged, partial, vin, sin, fin, vout, sout, fout,
+                                                               n_pad, runs, p, d);
+        return hipGetLastError();
+    }
     if (rank_merge) {
         uint16_t *partial = static_cast<uint16_t *>(scratch);
         const uint32_t group = rank_group(tile, tiles), groups = tiles / group;

@@ -281,11 +281,13 @@ def sort_case(P, rng):
     return f
 
 
-# covers every sort plan: one LDS tile (<= 4096), 1024-key tiles + rank merge (<= 131072, with and
-# without padding keys), 4096-key tiles + rank merge (262144), global bitonic fallback (> 1M)
+# covers every sort plan: one LDS tile (<= 4096), 1024-key tiles + one rank level (<= 65536, with and
+# without padding keys), 1024-key tiles merged into runs of 8192 + a rank level over the runs (131072
+# to 1M, with and without padding keys), global bitonic fallback (> 1M)
 @pytest.mark.parametrize("parents,offspring,block", [
     (16, 16, 32), (64, 192, 32), (24, 72, 32), (256, 768, 32), (1024, 3072, 32), (2048, 6144 + 32, 32),
-    (16384, 49152, 32), (65536, 196608, 32), (262144, 786432 + 32, 32)])
+    (16384, 49152, 32), (32768, 98304, 32), (40000, 110016, 32), (65536, 196608, 32), (262144, 786432, 32),
+    (262144, 786432 + 32, 32)])
 def test_sort_matches_stable_oracle(pkg, O, parents, offspring, block):
     es, _ = make_pair(pkg, O, parents, offspring, 0, 10, block=block)
     rng = np.random.default_rng(parents)
