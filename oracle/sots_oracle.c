@@ -19,7 +19,7 @@
  *  (6) counter-based Philox4x32-10 instead of wall-clock-seeded MWC64X;
  *  (7) scaleParams = min + v*(max-min) (ocl_program.cl:297); equals the CPU's
  *      v*max for the shipped mins = 0;
- *  (8) wavetable index clamped to [0, W-1]: the reference reads out of bounds
+ *  (8) wavetable index clamped to [0, W-1] (NaN -> 0): the reference reads out of bounds
  *      when a wrapped phase rounds to exactly W or a phase step exceeds W.
  */
 #include "sots_oracle.h"
@@ -107,10 +107,12 @@ uint32_t sots_or_synth_dims(uint32_t kind)
 
 static inline float tab_at(const float *table, float pos)
 {
-    int32_t i = (int32_t)pos; /* (unsigned int)pos for every in-range phase */
-    if (i < 0) i = 0;
-    if (i > (int32_t)SOTS_OR_WAVETABLE_SIZE - 1) i = (int32_t)SOTS_OR_WAVETABLE_SIZE - 1;
-    return table[i];
+    /* (unsigned int)pos for every in-range phase.  The clamp is decided on the float so that it is
+     * defined for every value (a phase beyond +-2^31 would make the C conversion undefined): at or
+     * beyond W -> W-1, negative or NaN -> 0; the device's saturating v_cvt_i32_f32 + clamp agrees. */
+    if (pos >= (float)SOTS_OR_WAVETABLE_SIZE) return table[SOTS_OR_WAVETABLE_SIZE - 1];
+    if (!(pos > 0.0f)) return table[0];
+    return table[(int32_t)pos];
 }
 
 #define WRAP_HI(p) do { if ((p) >= wsize) (p) -= wsize; } while (0)

@@ -222,9 +222,11 @@ private:
     }
     float tableAt(float pos) const
     {
-        int32_t i = (int32_t)pos;
-        i = std::min(std::max(i, 0), (int32_t)wavetableSize - 1); // [fix] the reference can index one past the table
-        return wavetable[i];
+        // [fix] the reference can index past the table; clamp decided on the float so that it is
+        // defined for every phase value (at or beyond the table length -> last entry, negative or NaN -> 0)
+        if (pos >= (float)wavetableSize) return wavetable[wavetableSize - 1];
+        if (!(pos > 0.0f)) return wavetable[0];
+        return wavetable[(int32_t)pos];
     }
     void advance(float &pos, float by, bool bothEnds) const
     {
