@@ -307,7 +307,10 @@ def test_sort_matches_stable_oracle(pkg, O, parents, offspring, block):
     es.close()
 
 
-@pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (3, 12, 32, 96), (2, 10, 32, 96)])
+# the last case is large enough (>= 192 individuals per CU, 4 genes) for the fused loop to make its
+# individuals inside the synthesis kernel, with a partly filled last tile
+@pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (3, 12, 32, 96), (2, 10, 32, 96),
+                                                          (0, 9, 16416, 49152)])
 def test_fused_generation_equals_staged(pkg, O, kind, log2n, parents, offspring):
     a, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
     b, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
