@@ -3,12 +3,17 @@
 
 A "step" is one generation (recombine+mutate | synthesise+window | FFT+fitness | sort |
 rotate, plus the elite all-gather when N > 1) over one island's whole population.
-Workload at N = 1: BASELINE.json configs[2] -- pop = 65536 (16384 parents + 49152
-offspring), 2-operator FM, 1024-sample / 1024-pt FFT, fp32, synthetic target
-(1450 Hz, I = 3, 200 Hz, A = 1).  N > 1: one island of that size per GPU (weak scaling),
-one process per GPU, elites all-gathered over RCCL every generation.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+Workloads (`--config`, BASELINE.json configs[] index; synthetic targets, fp32):
+  2  pop = 65536 (16384 parents + 49152 offspring) PER GPU, 2-operator FM, 1024-pt FFT:
+     the single-GPU configuration the metric is quoted on; N > 1 = one such island per GPU (weak)
+  3  pop = 262144 IN TOTAL, 4-operator FM, 4096-pt FFT, 16 elites per island: 262144/N per GPU (strong)
+  4  pop = 1048576 IN TOTAL, 2-operator FM, 1024-pt FFT: 1048576/N per GPU (strong)
+Default: config 2 at --gpus 1, config 4 at --gpus N > 1 (north_star: one MI355X at pop = 65536,
+the 8-GPU island model at pop = 1048576).  One process per GPU, elites all-gathered over RCCL
+every generation.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4}]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -44,6 +49,42 @@ VOICES = {
     "4op_series": ([3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0], [0.3, 0.25, 0.85, 0.19, 0.89, 0.125, 0.5, 0.1]),
     "triple_parallel": ([3520.0, 8.0, 3520.0, 1.0], [0.41, 0.375, 0.057, 1.0, 0.2, 0.5, 0.11, 0.7, 0.6, 0.1, 0.3, 0.4]),
 }
+
+BASELINE_CONFIGS = {
+    2: dict(total=None, per_gpu=65536, synth="2op", log2n=10, elites=16, scaling="weak",
+            text="pop=65536, 2-op FM, 1024-pt FFT, 1xMI355X - HBM-bound run, rocprof GB/s vs roofline"),
+    3: dict(total=262144, per_gpu=None, synth="4op_series", log2n=12, elites=16, scaling="strong",
+            text="pop=262144, 4-op FM, 4096-pt FFT, island-sharded across 8xMI355X with RCCL elite allgather over xGMI"),
+    4: dict(total=1048576, per_gpu=None, synth="2op", log2n=10, elites=16, scaling="strong",
+            text="pop=1,048,576, 2-op FM, 1024-pt FFT, 8xMI355X island model, per-GPU counter-based PRNG, 10k generations"),
+}
+
+
+def resolve_workload(config, gpus, parents=None, offspring=None, synth=None, log2n=None, elites=None, shard_of=None):
+    """(parents, offspring, synth, log2n, elites, scaling, label) of one island for --config / --gpus;
+    explicit --parents/--offspring/--synth/--log2n override the preset (the label then says so)."""
+    if config is None:
+        config = 2 if gpus == 1 else 4
+    c = BASELINE_CONFIGS[config]
+    shards = shard_of or gpus  # --shard-of G: this run's islands are G-GPU shards (profiling one shard on one GPU)
+    per_gpu = c["per_gpu"] if c["total"] is None else c["total"] // shards
+    if c["total"] is not None and c["total"] % (shards * 128) != 0:
+        raise SystemExit(f"--config {config}: {c['total']} candidates do not shard over {gpus} GPUs in blocks of 128")
+    custom = any(x is not None for x in (parents, offspring, synth, log2n))
+    if parents is None and offspring is None:
+        parents, offspring = per_gpu // 4, per_gpu - per_gpu // 4     # the 1 : 3 split of configs[2]
+    elif parents is None or offspring is None:
+        raise SystemExit("--parents and --offspring go together")
+    synth = synth or c["synth"]
+    log2n = log2n or c["log2n"]
+    elites = c["elites"] if elites is None else elites
+    p = parents + offspring
+    label = (f"custom: " if custom else f"BASELINE configs[{config}]: {c['text']} -> ")
+    if shard_of and shard_of != gpus and c["total"] is not None:
+        label += f"[the per-GPU shard of a {shard_of}-GPU run] "
+    label += (f"pop={p} ({parents}+{offspring}) per GPU x {gpus} island{'s' if gpus > 1 else ''} = {p * gpus}, "
+              f"{synth} FM, {1 << log2n}-sample / {1 << log2n}-pt FFT, fp32")
+    return parents, offspring, synth, log2n, elites, (c["scaling"] if not custom else "weak"), label, config
 
 
 def make_target(pkg, voice, log2n, device):
@@ -110,11 +151,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--parents", type=int, default=16384)
-    ap.add_argument("--offspring", type=int, default=49152)
-    ap.add_argument("--log2n", type=int, default=10)
-    ap.add_argument("--elites", type=int, default=16)
-    ap.add_argument("--synth", default="2op", choices=sorted(VOICES))
+    ap.add_argument("--config", type=int, default=None, choices=sorted(BASELINE_CONFIGS),
+                    help="BASELINE.json configs[] index (default: 2 at --gpus 1, 4 at --gpus N > 1)")
+    ap.add_argument("--parents", type=int, default=None)
+    ap.add_argument("--offspring", type=int, default=None)
+    ap.add_argument("--log2n", type=int, default=None)
+    ap.add_argument("--elites", type=int, default=None)
+    ap.add_argument("--synth", default=None, choices=sorted(VOICES))
+    ap.add_argument("--shard-of", type=int, default=None,
+                    help="size the islands as the per-GPU shards of a G-GPU run of configs 3/4 (e.g. --config 3 --shard-of 8 "
+                         "on one GPU = one 32768-candidate island)")
+    ap.add_argument("--sustain", type=float, default=1.0,
+                    help="seconds the loop keeps running after the headline region for the `sustained` record (0 = skip)")
     ap.add_argument("--sync-migration", action="store_true",
                     help="inject elites inside the generation that gathered them (default: the all-gather "
                          "overlaps the next generation and its rows arrive one generation later)")
@@ -122,9 +170,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --share-gpu rehearses N > 1 on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank to cuda:0 (rehearsal only)")
-    ap.add_argument("--timing-every", type=int, default=16,
-                    help="record per-kernel HIP events on every k-th timed step only (0 = never)")
+    ap.add_argument("--timing-every", type=int, default=None,
+                    help="record per-kernel HIP events on every k-th timed step (default max(1, steps // 8): "
+                         "at least 8 launches behind every per-kernel figure; 0 = never)")
     args = ap.parse_args()
+    (args.parents, args.offspring, args.synth, args.log2n, args.elites, scaling, workload, config_id) = resolve_workload(
+        args.config, args.gpus, args.parents, args.offspring, args.synth, args.log2n, args.elites, args.shard_of)
+    if args.timing_every is None:
+        args.timing_every = max(1, args.steps // 8)
 
     import torch
     import torch.distributed as dist
@@ -169,6 +222,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    c = pkg.capi
+    KERNELS = (
+        # Algorithmic bytes per candidate of the FUSED loop's kernels: what each
+        # kernel must move, not what the reference's stage-separated pipeline moves
+        # (B_alg = 24N+16 with the window round trip and the spectrum written out).
+        ("recombine+mutate", c.STAGE_FUSED_VARIATION, 16 * es.D),
+        ("synthesise", c.STAGE_FUSED_SYNTH, 4 * N + 4 * es.D),       # parameters in, audio row out
+        ("window+FFT+fitness", c.STAGE_FUSED_SPECTRAL, 4 * N + 4),   # audio row in, fitness out
+        ("sortPopulation", c.STAGE_SORT, 16 + 8 * (2 * es.D + 1)))
+
+    def harvest():
+        """per-kernel device time since the last timing_reset (HIP events on the launch stream)"""
+        ks = {}
+        for name, stage, alg_bytes in KERNELS:
+            ms, cnt = es.stage_time_ms(stage)
+            if cnt:
+                ks[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt), "alg_bytes_per_candidate": alg_bytes}
+        if "recombine+mutate" not in ks and "synthesise" in ks:
+            # large 4-gene populations: the synthesis kernel makes its own individuals (DESIGN.md 4)
+            ks["synthesise"]["alg_bytes_per_candidate"] += 16 * es.D
+            ks["synthesise"]["includes"] = "recombine+mutate"
+        return ks
+
     with torch.cuda.stream(stream):
         es.init_population(0)
         for _ in range(args.warmup):
@@ -181,34 +257,47 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
+        es.timing_enable(False)
+        kernels = harvest()
+        # `sustained`: the same loop keeps going for >= --sustain seconds (headline fields above are
+        # not touched by it): what a long run settles at once clocks and caches have
+        sustained = None
+        if args.sustain > 0:
+            es.timing_reset()
+            chunk = max(8, args.steps)
+            every = max(1, chunk // 8)
+            done, t1 = 0, time.perf_counter()
+            stop = torch.zeros(1, dtype=torch.int32, device=device)
+            while True:
+                for k in range(chunk):
+                    es.timing_enable(k % every == 0)
+                    step()
+                done += chunk
+                torch.cuda.synchronize(device)
+                stop[0] = 1 if time.perf_counter() - t1 >= args.sustain else 0
+                if world > 1:
+                    dist.all_reduce(stop, op=dist.ReduceOp.MAX)  # every rank leaves after the same chunk
+                if int(stop.item()):
+                    break
+            fence()
+            dt_s = time.perf_counter() - t1
+            es.timing_enable(False)
+            sustained = {"steps": done, "seconds": dt_s, "kernels": harvest()}
         island.finish()
     es.timing_enable(False)
 
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dt_t = torch.tensor([dt, sustained["seconds"] if sustained else 0.0], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt_max = float(dt_t.item())
+    dt_max = float(dt_t[0].item())
+    if sustained:
+        sustained["seconds"] = float(dt_t[1].item())
+        sustained["value"] = P * world * sustained["steps"] / sustained["seconds"]
+        sustained["unit"] = "candidates/s"
+        sustained["ms_per_step"] = 1e3 * sustained["seconds"] / sustained["steps"]
 
-    # per-kernel device time (HIP events on the launch stream, recorded inside the timed region)
-    c = pkg.capi
-    kernels = {}
-    for name, stage, alg_bytes in (
-            # Algorithmic bytes per candidate of the FUSED loop's kernels: what each
-            # kernel must move, not what the reference's stage-separated pipeline moves
-            # (B_alg = 24N+16 with the window round trip and the spectrum written out).
-            ("recombine+mutate", c.STAGE_FUSED_VARIATION, 16 * es.D),
-            ("synthesise", c.STAGE_FUSED_SYNTH, 4 * N + 4 * es.D),       # parameters in, audio row out
-            ("window+FFT+fitness", c.STAGE_FUSED_SPECTRAL, 4 * N + 4),   # audio row in, fitness out
-            ("sortPopulation", c.STAGE_SORT, 16 + 8 * (2 * es.D + 1))):
-        ms, cnt = es.stage_time_ms(stage)
-        if cnt:
-            kernels[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt), "alg_bytes_per_candidate": alg_bytes}
-    if "recombine+mutate" not in kernels and "synthesise" in kernels:
-        # large 4-gene populations: the synthesis kernel makes its own individuals
-        kernels["synthesise"]["alg_bytes_per_candidate"] += 16 * es.D
-        kernels["synthesise"]["includes"] = "recombine+mutate"
     fitness = es.read_fitness()
-    best = float(fitness[0])
+    best = float(np.nanmin(fitness))  # immigrants injected after the last sort sit in the parent tail, so row 0 need not be the best
     # What crossing the boundary with HOST buffers would cost (never part of `value`): a blocking
     # read of the whole population (values, steps, fitness) through the C-ABI, as a caller would do
     # that inspects every generation; the product path itself keeps the population in HBM.
@@ -226,9 +315,10 @@ def main():
         # only valid for the configuration they were collected on
         pmc = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and P == 65536 and N == 1024:
+        wkey = f"P{P}_N{N}_{args.synth}"
+        if os.path.exists(tpath):
             try:
-                pmc = json.load(open(tpath))
+                pmc = json.load(open(tpath)).get("workloads", {}).get(wkey, {})
             except Exception:
                 pmc = {}
         traffic = pmc.get(dom)
@@ -247,12 +337,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{'BASELINE configs[2]: ' if (P, N, args.synth) == (65536, 1024, '2op') else ''}pop={P} ({args.parents}+{args.offspring}) per GPU, {args.synth} FM, "
-                                   f"{N}-sample / {N}-pt FFT, fp32",
+            "config": {"workload": workload, "baseline_config": config_id,
                        "islands": world, "elites_per_island": args.elites if world > 1 else 0,
                        "migration_interval": 1,
                        "migration": "none" if world == 1 else ("same generation" if args.sync_migration else "overlapped, arrives one generation later"),
@@ -264,7 +353,8 @@ def main():
                                   "and is an effective bandwidth that exceeds 1 once stages are fused",
                          "achieved_b_alg_share": B_ALG_SHARE[dom](N, es.D) * P / (dk["avg_us"] * 1e-6) / 1e9,
                          "frac_b_alg_share": B_ALG_SHARE[dom](N, es.D) * P / (dk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" if traffic else None,
+                         "traffic_source": f"profiles/pmc_traffic.json[{wkey}] (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" if traffic else None,
+                         "launches": dk["launches"],
                          "avg_kernel_us": dk["avg_us"],
                          "alg_bytes_per_launch": dk["alg_bytes_per_candidate"] * P},
             "pipeline_effective": {"b_alg_unfused_bytes_per_candidate": b_alg,
@@ -282,6 +372,7 @@ def main():
                                        "the target (4N bytes in) and the final population"},
             "kernels": kernels,
             "roofline_per_kernel": per_kernel,
+            "sustained": sustained,
             "best_fitness_sse": best,
             "best_fitness_mse": best / (N // 2),
         }

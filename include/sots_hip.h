@@ -156,12 +156,18 @@ int sots_timing_reset(sots_ctx *ctx);
 /* sum of hipEvent-measured durations and the number of launches of that stage
  * since the last reset; synchronises the stream */
 int sots_stage_time_ms(sots_ctx *ctx, int stage, double *total_ms, uint64_t *count);
+/* the individual launch durations behind that sum, oldest first (at most 65536 are kept per stage
+ * between resets): one Benchmarker::addTimer(name, ms) per launch gives the CSV the reference's
+ * per-launch Average/Max/Min columns (Benchmarker.hpp:33-72,109-130).  *written <= capacity. */
+int sots_stage_launch_times_ms(sots_ctx *ctx, int stage, float *out_ms, uint64_t capacity, uint64_t *written);
 
 /* ---- island model (new) ----
  * A row is [fitness, v0..v(D-1), s0..s(D-1)] = (2D+1) floats.  pack copies the best
- * n_rows rows of the current (sorted) half; inject overwrites the last n_rows
- * PARENT rows (numParents-n_rows .. numParents-1) so that immigrants take part
- * in the next recombination.  *_device take device pointers on this context's
+ * n_rows rows of the current (sorted) half; inject overwrites the last n_rows of the
+ * PARENT rows that recombination reads - whole blocks of workgroupSize rows:
+ * B = max(1, numParents / workgroupSize) * workgroupSize, rows B-n_rows .. B-1
+ * (= numParents-n_rows .. numParents-1 when numParents is a multiple of the block,
+ * ocl_program.cl:99-112) - so that immigrants take part in the next recombination.  *_device take device pointers on this context's
  * device and run on its stream (no host sync); *_host are blocking. */
 int sots_pack_elites_device(sots_ctx *ctx, void *device_rows, uint32_t n_rows);
 int sots_inject_immigrants_device(sots_ctx *ctx, const void *device_rows, uint32_t n_rows);

@@ -614,7 +614,10 @@ void sots_or_es_generation(sots_or_es *es)
 void sots_or_es_inject(sots_or_es *es, const float *rows, uint32_t n_rows)
 {
     const uint32_t d = es->d, w = 2 * d + 1;
-    const uint32_t first = es->cfg.num_parents - n_rows;
+    /* tail of the rows recombination reads: whole blocks of parents (ocl_program.cl:99-112) */
+    uint32_t npb = es->cfg.num_parents / es->cfg.recomb_block;
+    if (npb == 0) npb = 1;
+    const uint32_t first = npb * es->cfg.recomb_block - n_rows;
     for (uint32_t r = 0; r < n_rows; ++r) {
         const float *row = rows + (size_t)r * w;
         es->fitness[first + r] = row[0];

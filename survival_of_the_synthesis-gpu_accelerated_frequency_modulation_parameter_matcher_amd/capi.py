@@ -41,6 +41,7 @@ EXPORTS = [
     "sots_stage_fft", "sots_stage_fitness", "sots_stage_sort", "sots_stage_rotate",
     "sots_execute_generation", "sots_execute_generations", "sots_get_generation",
     "sots_set_generation", "sots_timing_enable", "sots_timing_reset", "sots_stage_time_ms",
+    "sots_stage_launch_times_ms",
     "sots_pack_elites_device", "sots_inject_immigrants_device", "sots_inject_gathered_device", "sots_pack_elites_host",
     "sots_inject_immigrants_host", "sots_get_info",
 ]
@@ -110,6 +111,7 @@ def load():
     L.sots_timing_enable.argtypes = [vp, C.c_int]
     L.sots_timing_reset.argtypes = [vp]
     L.sots_stage_time_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sots_stage_launch_times_ms.argtypes = [vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sots_pack_elites_device.argtypes = [vp, vp, u32]
     L.sots_inject_immigrants_device.argtypes = [vp, vp, u32]
     L.sots_inject_gathered_device.argtypes = [vp, vp, u32, u32, u32]
@@ -297,6 +299,12 @@ class HipES:
         t, c = C.c_double(), C.c_uint64()
         self._check(self.L.sots_stage_time_ms(self._h, stage, C.byref(t), C.byref(c)))
         return t.value, c.value
+
+    def stage_launch_times_ms(self, stage, capacity=65536):
+        out = np.empty(capacity, np.float32)
+        n = C.c_uint64()
+        self._check(self.L.sots_stage_launch_times_ms(self._h, stage, _ptr(out), capacity, C.byref(n)))
+        return out[:n.value].copy()
 
     # -- island exchange --
     def pack_elites_device(self, dev_ptr, n_rows):

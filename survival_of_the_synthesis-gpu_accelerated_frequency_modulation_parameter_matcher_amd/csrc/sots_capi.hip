@@ -24,7 +24,9 @@ struct StageClock {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spare;
     double total_ms = 0.0;
     uint64_t count = 0;
+    std::vector<float> launches_ms; // per-launch durations since the last reset (bounded: kMaxLaunchSamples)
 };
+constexpr size_t kMaxLaunchSamples = 1u << 16;
 
 thread_local std::string g_create_error;
 
@@ -50,6 +52,11 @@ struct sots_ctx {
     uint64_t *keys = nullptr;
     void *sort_scratch = nullptr;
     uint32_t rows_capacity = 0;
+    OccCache occ{};
+    // experiment switches; fixed in the shipped library, settable from the environment only in a
+    // -DSOTS_EXPERIMENT build (tools/exp_*.sh)
+    bool allow_cut = true;
+    int fuse_variation = -1; // -1: by population shape, 0 / 1: forced
     // host tables
     std::vector<double> window64;
     float window_factor = 1.0f, inv_n = 0.0f, inv_wf = 1.0f;
@@ -145,6 +152,7 @@ int drain_clock(sots_ctx *ctx, StageClock &ck)
         SOTS_HIP(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
         ck.total_ms += ms;
         ck.count += 1;
+        if (ck.launches_ms.size() < kMaxLaunchSamples) ck.launches_ms.push_back(ms);
         ck.spare.push_back(ev);
     }
     ck.pending.clear();
@@ -189,6 +197,18 @@ int ensure_rows(sots_ctx *ctx, uint32_t n_rows)
     SOTS_HIP(ctx, hipMalloc((void **)&ctx->rows, (size_t)n_rows * (2 * ctx->D + 1) * sizeof(float)));
     ctx->rows_capacity = n_rows;
     return SOTS_OK;
+}
+
+// Rows of the sorted half that the next recombination reads (recombine_source, sots_kernels.hip):
+// whole blocks of parents, floor(numParents / block) of them, at least one.  Immigrants go to the
+// tail of THESE rows: with numParents not a multiple of the block, rows between the last whole
+// block and numParents are never read and immigrants written there would be dead.
+uint32_t breeding_rows(const sots_ctx *ctx)
+{
+    const uint32_t block = ctx->pd.block;
+    uint32_t npb = ctx->cfg.num_parents / block;
+    if (npb == 0) npb = 1;
+    return npb * block;
 }
 
 int require_target(sots_ctx *ctx)
@@ -266,10 +286,13 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     ctx->N = 1u << ctx->log2n;
     ctx->n_pad = next_pow2(ctx->P < 2 ? 2 : ctx->P);
     {
-        // audio rows are padded off the power-of-two stride (see sots_kernels.h); SOTS_AUDIO_PAD
-        // (floats, multiple of 4) overrides the default for experiments
+        // audio rows are padded off the power-of-two stride (see sots_kernels.h)
         uint32_t pad = 32;
-        if (const char *e = getenv("SOTS_AUDIO_PAD")) pad = (uint32_t)strtoul(e, nullptr, 10) & ~3u;
+#ifdef SOTS_EXPERIMENT
+        if (const char *e = getenv("SOTS_AUDIO_PAD")) pad = (uint32_t)strtoul(e, nullptr, 10) & ~3u; // floats
+        if (const char *e = getenv("SOTS_SYNTH_CUT")) ctx->allow_cut = atoi(e) != 0;                 // 0: never cut the chain
+        if (const char *e = getenv("SOTS_FUSE_VARIATION")) ctx->fuse_variation = atoi(e) != 0 ? 1 : 0;
+#endif
         ctx->pitch = ctx->N + pad;
     }
     ctx->pd = PopDims{ctx->P, ctx->D, cfg->num_parents, cfg->workgroup_size, cfg->gid_base,
@@ -492,7 +515,7 @@ int sots_stage_synthesise(sots_ctx *ctx)
     {
         StageScope t(ctx, SOTS_STAGE_SYNTHESISE);
         SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable,
-                                   ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
+                                   ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus, nullptr, ctx->allow_cut));
     }
     return maybe_drain(ctx);
 }
@@ -514,7 +537,7 @@ int sots_stage_fft(sots_ctx *ctx)
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_FFT);
-        SOTS_HIP(ctx, launch_fft(ctx->stream, ctx->audio, ctx->spectrum, ctx->twiddle, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus));
+        SOTS_HIP(ctx, launch_fft(ctx->stream, ctx->audio, ctx->spectrum, ctx->twiddle, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus, &ctx->occ));
     }
     return maybe_drain(ctx);
 }
@@ -527,7 +550,7 @@ int sots_stage_fitness(sots_ctx *ctx)
     {
         StageScope t(ctx, SOTS_STAGE_FITNESS);
         SOTS_HIP(ctx, launch_fitness(ctx->stream, ctx->spectrum, ctx->target, ctx->fit(ctx->rot), ctx->P, ctx->log2n,
-                                     ctx->inv_n, ctx->inv_wf, ctx->num_cus));
+                                     ctx->inv_n, ctx->inv_wf, ctx->num_cus, &ctx->occ));
     }
     return maybe_drain(ctx);
 }
@@ -581,12 +604,8 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         // Large populations of 4-gene individuals make their individuals inside the synthesis kernel
         // (one launch less, 151 vs 157 us per generation at P = 65536); with few wavefronts per CU or
         // more genes the serial per-lane variation costs more than the launch it saves (measured).
-        static const int fuse_env = [] {
-            const char *e = getenv("SOTS_FUSE_VARIATION"); // 0 / 1 force it off / on (A/B profiling)
-            return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-        }();
-        const bool fuse_variation = fuse_env >= 0 ? fuse_env == 1
-                                                  : (ctx->pd.d <= 4 && ctx->P >= 192u * (ctx->num_cus ? ctx->num_cus : 256u));
+        const bool fuse_variation = ctx->fuse_variation >= 0 ? ctx->fuse_variation == 1
+                                                             : (ctx->pd.d <= 4 && ctx->P >= 192u * (ctx->num_cus ? ctx->num_cus : 256u));
         if (!fuse_variation) {
             StageScope t(ctx, SOTS_STAGE_FUSED_VARIATION);
             SOTS_HIP(ctx, launch_recombine_mutate(ctx->stream, ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst),
@@ -600,12 +619,12 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
             sots::Variation var = {ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst), ctx->pd, ctx->mc, ctx->generation};
             SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable,
                                        ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus,
-                                       fuse_variation ? &var : nullptr));
+                                       fuse_variation ? &var : nullptr, ctx->allow_cut));
         }
         {
             StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL);
             SOTS_HIP(ctx, launch_fft_fitness(ctx->stream, ctx->audio, ctx->window, ctx->target, ctx->fit(ctx->rot), ctx->twiddle, ctx->P,
-                                             ctx->log2n, ctx->pitch, ctx->inv_n, ctx->inv_wf, ctx->num_cus));
+                                             ctx->log2n, ctx->pitch, ctx->inv_n, ctx->inv_wf, ctx->num_cus, &ctx->occ));
         }
         src = ctx->rot;
         dst = ctx->rot ^ 1u;
@@ -652,6 +671,7 @@ int sots_timing_reset(sots_ctx *ctx)
         if (int rc = drain_clock(ctx, ck)) return rc;
         ck.total_ms = 0.0;
         ck.count = 0;
+        ck.launches_ms.clear();
     }
     return SOTS_OK;
 }
@@ -664,6 +684,20 @@ int sots_stage_time_ms(sots_ctx *ctx, int stage, double *total_ms, uint64_t *cou
     if (int rc = drain_clock(ctx, ctx->clocks[stage])) return rc;
     if (total_ms) *total_ms = ctx->clocks[stage].total_ms;
     if (count) *count = ctx->clocks[stage].count;
+    return SOTS_OK;
+}
+
+int sots_stage_launch_times_ms(sots_ctx *ctx, int stage, float *out_ms, uint64_t capacity, uint64_t *written)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (stage < 0 || stage >= SOTS_STAGE_COUNT) return fail(ctx, SOTS_ERR_INVALID, "stage %d out of range", stage);
+    if (!written || (capacity && !out_ms)) return fail(ctx, SOTS_ERR_INVALID, "stage_launch_times: null argument");
+    if (int rc = bind_device(ctx)) return rc;
+    if (int rc = drain_clock(ctx, ctx->clocks[stage])) return rc;
+    const std::vector<float> &v = ctx->clocks[stage].launches_ms;
+    const uint64_t n = v.size() < capacity ? v.size() : capacity;
+    for (uint64_t i = 0; i < n; ++i) out_ms[i] = v[i];
+    *written = n;
     return SOTS_OK;
 }
 
@@ -681,11 +715,11 @@ int sots_pack_elites_device(sots_ctx *ctx, void *device_rows, uint32_t n_rows)
 int sots_inject_immigrants_device(sots_ctx *ctx, const void *device_rows, uint32_t n_rows)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (!device_rows || n_rows > ctx->cfg.num_parents)
-        return fail(ctx, SOTS_ERR_INVALID, "inject_immigrants: %u rows do not fit %u parents", n_rows, ctx->cfg.num_parents);
+    if (!device_rows || n_rows > breeding_rows(ctx))
+        return fail(ctx, SOTS_ERR_INVALID, "inject_immigrants: %u rows do not fit the %u parent rows recombination reads", n_rows, breeding_rows(ctx));
     if (int rc = bind_device(ctx)) return rc;
     SOTS_HIP(ctx, launch_unpack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
-                                     (const float *)device_rows, ctx->cfg.num_parents - n_rows, n_rows, ctx->D, 0, 0));
+                                     (const float *)device_rows, breeding_rows(ctx) - n_rows, n_rows, ctx->D, 0, 0));
     return SOTS_OK;
 }
 
@@ -695,12 +729,12 @@ int sots_inject_gathered_device(sots_ctx *ctx, const void *gathered_rows, uint32
     if (!gathered_rows || world == 0 || rank >= world)
         return fail(ctx, SOTS_ERR_INVALID, "inject_gathered: bad arguments (world %u, rank %u)", world, rank);
     const uint64_t n_rows = (uint64_t)(world - 1) * elites;
-    if (n_rows > ctx->cfg.num_parents)
-        return fail(ctx, SOTS_ERR_INVALID, "inject_gathered: %llu immigrant rows do not fit %u parents",
-                    (unsigned long long)n_rows, ctx->cfg.num_parents);
+    if (n_rows > breeding_rows(ctx))
+        return fail(ctx, SOTS_ERR_INVALID, "inject_gathered: %llu immigrant rows do not fit the %u parent rows recombination reads",
+                    (unsigned long long)n_rows, breeding_rows(ctx));
     if (int rc = bind_device(ctx)) return rc;
     SOTS_HIP(ctx, launch_unpack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
-                                     (const float *)gathered_rows, ctx->cfg.num_parents - (uint32_t)n_rows, (uint32_t)n_rows,
+                                     (const float *)gathered_rows, breeding_rows(ctx) - (uint32_t)n_rows, (uint32_t)n_rows,
                                      ctx->D, rank * elites, elites));
     return SOTS_OK;
 }

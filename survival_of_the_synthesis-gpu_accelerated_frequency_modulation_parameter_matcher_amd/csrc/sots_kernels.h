@@ -47,6 +47,14 @@ struct Variation {
     uint32_t generation;
 };
 
+// Resident-workgroup counts of the persistent spectral kernels (occupancy queries), cached per
+// CONTEXT: a context belongs to one device and is used from one thread at a time, so the cache
+// needs no synchronisation (a process-wide cache would be shared by every device and thread).
+struct OccCache {
+    int fft[16], fft_wg[16], fitness[16], fitness_wg[16];
+    int fused_win[16], fused_raw[16], fused_wg_win[16], fused_wg_raw[16];
+};
+
 // ---- variation ----
 hipError_t launch_init_population(hipStream_t st, float *values, float *steps, float *fitness,
                                   const PopDims &pd, uint32_t chunk);
@@ -64,19 +72,19 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 // would put every lane of a row-per-lane store on the same memory channel.
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
-                        uint32_t num_cus, const Variation *var = nullptr);
+                        uint32_t num_cus, const Variation *var = nullptr, bool allow_cut = true);
 hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint32_t p, uint32_t log2n,
                          uint32_t pitch);
 // audio[P][pitch] -> spectrum[P][N+8]
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
-                      uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus);
+                      uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus, OccCache *occ);
 // spectrum[P][N+8] x target[N/2] -> fitness[P]
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
-                          uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus);
+                          uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus, OccCache *occ);
 // audio[P][pitch] (x window when window != nullptr) x target -> fitness[P]; no spectrum in memory
 hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *window, const float *target,
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
-                              float inv_n, float inv_wf, uint32_t num_cus);
+                              float inv_n, float inv_wf, uint32_t num_cus, OccCache *occ);
 
 // ---- selection ----
 // keys: P_pad 64-bit words (P_pad = next power of two >= P); scratch: sort_scratch_bytes(P) bytes

@@ -1525,7 +1525,7 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
-                        uint32_t num_cus, const Variation *variation)
+                        uint32_t num_cus, const Variation *variation, bool allow_cut)
 {
     Variation var = {};
     if (variation) var = *variation;
@@ -1537,10 +1537,6 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     const uint32_t share = (p + cus - 1) / cus;
     uint32_t waves = (share + kWave - 1) / kWave;
     waves = waves < 1 ? 1 : waves > (uint32_t)kSynthWaves ? (uint32_t)kSynthWaves : waves;
-    static const bool allow_cut = [] {
-        const char *e = getenv("SOTS_SYNTH_CUT"); // 0: never cut the chain (A/B profiling)
-        return e ? atoi(e) != 0 : true;
-    }();
     const bool cut = allow_cut && waves <= 2 && kind != SOTS_SYNTH_TRIPLE_PAR;
     const uint32_t threads = (cut ? 2 : 1) * waves * kWave, grid = grid_for(p, waves * kWave, cus);
 #define SOTS_SYNTH_CASE(K, S)                                                                            \
@@ -1568,7 +1564,7 @@ hipError_t launch_window(hipStream_t st, float *audio, const float *window, uint
 }
 
 // Grid of a grid-stride kernel whose items all cost the same: exactly as many workgroups as
-// are resident at once (occupancy query, cached per kernel).  A larger grid runs in rounds
+// are resident at once (occupancy query, cached per kernel and per context: OccCache).  A larger grid runs in rounds
 // and the last, partly filled round costs as much as a full one (measured: 4096 one-wave
 // workgroups on 3072 slots took 1.5x the time of 3072).
 template <typename K>
@@ -1602,9 +1598,9 @@ static constexpr uint32_t wg_from() { return 11; }
     }
 
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
-                      uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus)
+                      uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus, OccCache *oc)
 {
-    static int occ[16] = {0}, occ_wg[16] = {0};
+    int *occ = oc->fft, *occ_wg = oc->fft_wg;
     if (log2n >= wg_from()) {
 #define CALL(L) k_fft_wg<L, 0, false><<<resident_grid(k_fft_wg<L, 0, false>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
         SOTS_DISPATCH_WG(log2n, CALL)
@@ -1618,9 +1614,9 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
 }
 
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
-                          uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus)
+                          uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
-    static int occ[16] = {0}, occ_wg[16] = {0};
+    int *occ = oc->fitness, *occ_wg = oc->fitness_wg;
     if (log2n >= wg_from()) {
 #define CALL(L) k_fitness_wg<L><<<resident_grid(k_fitness_wg<L>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
         SOTS_DISPATCH_WG(log2n, CALL)
@@ -1635,9 +1631,9 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
 
 hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *window, const float *target,
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
-                              float inv_n, float inv_wf, uint32_t num_cus)
+                              float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
-    static int occ_w[16] = {0}, occ_n[16] = {0}, occ_wgw[16] = {0}, occ_wgn[16] = {0};
+    int *occ_w = oc->fused_win, *occ_n = oc->fused_raw, *occ_wgw = oc->fused_wg_win, *occ_wgn = oc->fused_wg_raw;
     if (log2n >= wg_from()) {
         if (window) {
 #define CALL(L) k_fft_wg<L, 1, true><<<resident_grid(k_fft_wg<L, 1, true>, wg_threads<L>(), p, num_cus, &occ_wgw[L]), wg_threads<L>(), 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)

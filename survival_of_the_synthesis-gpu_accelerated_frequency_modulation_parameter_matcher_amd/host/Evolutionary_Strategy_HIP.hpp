@@ -14,10 +14,12 @@
 #ifndef SOTS_EVOLUTIONARY_STRATEGY_HIP_HPP
 #define SOTS_EVOLUTIONARY_STRATEGY_HIP_HPP
 
+#include <algorithm>
 #include <array>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/sots_hip.h"
 #include "Benchmarker.hpp"
@@ -39,6 +41,12 @@ struct Evolutionary_Strategy_HIP_Arguments
     uint32_t gidBase = 0;             // island offset of individual 0
     int32_t synthKind = -1;           // -1: derive from numDimensions (4, 6, 8, 12)
     bool fusedGenerations = true;     // executeAllGenerations uses the fused kernel loop
+    // general.isBenchmarking (parameters.json:7, main.cpp:85).  true: every launch is bracketed by a
+    // hipEvent pair and lands in the CSV under the reference's stage names (an event pair costs
+    // about 3.5 us per kernel boundary: 170 vs 144 us per generation at pop = 65536).  false: the
+    // un-instrumented loop - no events, one wall-clock "Total Audio Analysis Time" row and a
+    // candidates-per-second line ("plus an un-instrumented mode").
+    bool benchmarkStages = true;
     bool verbose = true;
     std::string logDirectory = "";    // where hiplog(...).csv goes ("" = cwd)
 };
@@ -59,6 +67,8 @@ private:
     uint32_t targetAudioLength = 0;
     std::vector<float> targetFFT_;
     std::vector<std::vector<float>> bestPerChunk_;
+    std::vector<float> launchScratch_;
+    double candidatesPerSecond_ = 0.0;
 
     Benchmarker hipBenchmarker_;
 
@@ -83,26 +93,35 @@ private:
         return dir + "hiplog(pop=" + std::to_string(a.es_args.pop.populationLength) + "gens=" + std::to_string(a.es_args.numGenerations) +
                "audioBlockSize=" + std::to_string(1u << a.es_args.audioLengthLog2) + ").csv";
     }
-    // hipEvent durations of the stages run since the last harvest -> Benchmarker
+    // hipEvent durations of the launches since the last harvest -> Benchmarker, ONE addTimer per
+    // launch, so that the CSV's Average/Max/Min/difference columns are per launch as in the
+    // reference (Benchmarker.hpp:33-72); launches beyond the library's per-stage sample store
+    // (65536 between harvests) are added as one remainder
+    void harvestStage(int stage, const std::string &name)
+    {
+        double ms = 0.0;
+        uint64_t n = 0, got = 0;
+        check(sots_stage_time_ms(ctx_, stage, &ms, &n), "sots_stage_time_ms");
+        if (!n) return;
+        launchScratch_.resize((size_t)std::min<uint64_t>(n, 65536));
+        check(sots_stage_launch_times_ms(ctx_, stage, launchScratch_.data(), launchScratch_.size(), &got), "sots_stage_launch_times_ms");
+        double listed = 0.0;
+        for (uint64_t i = 0; i < got; ++i) {
+            hipBenchmarker_.addTimer(name, launchScratch_[i]);
+            listed += launchScratch_[i];
+        }
+        if (got < n) hipBenchmarker_.addTimer(name, ms - listed);
+    }
     void harvestTimers()
     {
+        if (!args_.benchmarkStages) return;
         static const int stageOf[numKernels_] = {SOTS_STAGE_INIT, SOTS_STAGE_RECOMBINE, SOTS_STAGE_MUTATE, SOTS_STAGE_SYNTHESISE,
                                                  SOTS_STAGE_WINDOW, SOTS_STAGE_FFT, SOTS_STAGE_FITNESS, SOTS_STAGE_SORT, SOTS_STAGE_ROTATE};
-        for (uint8_t k = 0; k < numKernels_; ++k) {
-            double ms = 0.0;
-            uint64_t n = 0;
-            check(sots_stage_time_ms(ctx_, stageOf[k], &ms, &n), "sots_stage_time_ms");
-            if (n) hipBenchmarker_.addTimer(kernelNames_[k], ms);
-        }
+        for (uint8_t k = 0; k < numKernels_; ++k) harvestStage(stageOf[k], kernelNames_[k]);
         static const std::pair<int, const char *> fused[] = {{SOTS_STAGE_FUSED_VARIATION, "recombine+mutatePopulation"},
                                                              {SOTS_STAGE_FUSED_SYNTH, "synthesise+applyWindowPopulation"},
                                                              {SOTS_STAGE_FUSED_SPECTRAL, "hipFFT+fitnessPopulation"}};
-        for (const auto &f : fused) {
-            double ms = 0.0;
-            uint64_t n = 0;
-            check(sots_stage_time_ms(ctx_, f.first, &ms, &n), "sots_stage_time_ms");
-            if (n) hipBenchmarker_.addTimer(f.second, ms);
-        }
+        for (const auto &f : fused) harvestStage(f.first, f.second);
         check(sots_timing_reset(ctx_), "sots_timing_reset");
     }
 
@@ -127,6 +146,8 @@ public:
     sots_ctx *context() { return ctx_; }
     Benchmarker &benchmarker() { return hipBenchmarker_; }
     const std::vector<std::vector<float>> &bestParametersPerChunk() const { return bestPerChunk_; }
+    // candidates evaluated per second of the last parameterMatchAudio (population x generations x chunks / wall time)
+    double candidatesPerSecond() const { return candidatesPerSecond_; }
 
     void init() override
     {
@@ -152,7 +173,7 @@ public:
         const int rc = sots_create(&cfg_, &ctx_);
         if (rc != SOTS_OK) throw std::runtime_error(std::string("Evolutionary_Strategy_HIP: sots_create: ") + sots_last_error(nullptr));
         targetFFT_.assign(objective.fftHalfSize, 0.0f);
-        check(sots_timing_enable(ctx_, 1), "sots_timing_enable");
+        check(sots_timing_enable(ctx_, args_.benchmarkStages ? 1 : 0), "sots_timing_enable");
     }
     void initTargetAudio() override {}
 
@@ -235,6 +256,9 @@ public:
             harvestTimers();
         }
         hipBenchmarker_.pauseTimer("Total Audio Analysis Time");
+        const double totalMs = hipBenchmarker_.totalMs("Total Audio Analysis Time");
+        candidatesPerSecond_ = totalMs > 0.0 ? (double)population.populationLength * numGenerations * numChunks_ / (totalMs * 1e-3) : 0.0;
+        if (args_.verbose) printf("Candidates evaluated per second: %.6g\n", candidatesPerSecond_);
 
         for (uint8_t k = 1; k < numKernels_; ++k)
             if (hipBenchmarker_.count(kernelNames_[k])) hipBenchmarker_.elapsedTimer(kernelNames_[k]);

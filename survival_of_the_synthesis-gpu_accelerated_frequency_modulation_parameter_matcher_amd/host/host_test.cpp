@@ -92,6 +92,36 @@ int main(int argc, char **argv)
             if (line.rfind("Total Audio Analysis Time", 0) == 0) has_total = true;
         }
 
+        // un-instrumented mode (general.isBenchmarking = false): no stage rows, the total row, a rate
+        int quiet_rows = 0, quiet_stage_rows = 0;
+        bool quiet_total = false;
+        double quiet_rate = 0.0;
+        {
+            auto quiet = make_args(parents, offspring, 4, log2n, 5, pmax, dir);
+            quiet.benchmarkStages = false;
+            {
+                Evolutionary_Strategy_HIP q(quiet);
+                q.parameterMatchAudio(target.data(), n);
+                quiet_rate = q.candidatesPerSecond();
+            }
+            std::ifstream qin(dir + "/hiplog(pop=" + std::to_string(P) + "gens=5audioBlockSize=" + std::to_string(n) + ").csv");
+            std::string ql;
+            std::getline(qin, ql);
+            while (std::getline(qin, ql)) {
+                ++quiet_rows;
+                if (ql.rfind("Total Audio Analysis Time", 0) == 0) quiet_total = true;
+                else ++quiet_stage_rows;
+            }
+        }
+        // instrumented: the fused-loop rows are per launch (Average = Total / launches)
+        double avg_sort_ms = 0.0, total_sort_ms = 0.0;
+        {
+            std::ifstream cin2(csv);
+            std::string l2;
+            while (std::getline(cin2, l2))
+                if (l2.rfind("sortPopulation,", 0) == 0) sscanf(l2.c_str(), "sortPopulation,%lf,%lf", &total_sort_ms, &avg_sort_ms);
+        }
+
         // a bad configuration must throw, not limp on
         bool threw = false;
         try {
@@ -103,9 +133,11 @@ int main(int argc, char **argv)
 
         printf("{\"sorted\": %s, \"aos_ok\": %s, \"best_fitness_last_chunk\": %.9g, \"host_fitness_chunk0\": %.9g, "
                "\"chunks\": %zu, \"fused_equals_staged\": %s, \"csv_header\": \"%s\", \"csv_rows\": %d, \"csv_has_total\": %s, "
-               "\"bad_config_throws\": %s, \"staged_fft_pending\": %u}\n",
+               "\"bad_config_throws\": %s, \"staged_fft_pending\": %u, \"quiet_rows\": %d, \"quiet_stage_rows\": %d, "
+               "\"quiet_has_total\": %s, \"quiet_candidates_per_s\": %.6g, \"sort_total_ms\": %.9g, \"sort_avg_ms\": %.9g}\n",
                sorted ? "true" : "false", aos_ok ? "true" : "false", f[0], host_fit, best.size(), same ? "true" : "false",
-               header.c_str(), rows, has_total ? "true" : "false", threw ? "true" : "false", staged_fft_calls);
+               header.c_str(), rows, has_total ? "true" : "false", threw ? "true" : "false", staged_fft_calls, quiet_rows,
+               quiet_stage_rows, quiet_total ? "true" : "false", quiet_rate, total_sort_ms, avg_sort_ms);
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "host_test failed: %s\n", e.what());

@@ -147,6 +147,9 @@ static std::vector<float> readAudioFile(const std::string &path)
         const uint32_t len = rd32(&d[pos + 4]);
         const unsigned char *body = &d[pos + 8];
         if (!memcmp(&d[pos], "fmt ", 4) && len >= 16) {
+            // the fields read below must lie inside the file (a truncated or odd 44-45 byte file ends
+            // inside the chunk): 16 bytes of PCM header, 26 when the extensible sub-format is read
+            if (pos + 8 + std::min<size_t>(len, 26) > d.size()) throw std::runtime_error(path + ": truncated fmt chunk");
             fmt = rd16(body);
             channels = rd16(body + 2);
             bits = rd16(body + 14);
@@ -237,6 +240,8 @@ int main(int argc, char *argv[])
         args.es_args.paramMax = evo["paramMaxs"].floats();
         args.es_args.audioLengthLog2 = audioLengthLog2;
         args.verbose = verbose;
+        // general.isBenchmarking (parameters.json:7, main.cpp:85): per-stage hipEvent timing on / off
+        if (j["general"].has("isBenchmarking")) args.benchmarkStages = j["general"]["isBenchmarking"].b;
         if (j["type"].has("HIP")) {
             const Json &h = j["type"]["HIP"];
             if (h.has("workgroupSize")) args.workgroupX = (uint32_t)h["workgroupSize"].number();

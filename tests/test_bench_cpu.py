@@ -51,3 +51,31 @@ def test_b_alg_shares_add_up_to_the_survey_figure():
     for n in (1024, 4096):
         evaluation = sum(bench.B_ALG_SHARE[k](n, 4) for k in ("synthesise", "window+FFT+fitness"))
         assert evaluation == 24 * n + 16  # B_alg without the O(D) population traffic
+
+
+def test_config_presets_name_the_baseline_workloads():
+    """bench.py --config: BASELINE.json configs[2..4] as stated; the default is
+    config 2 on one GPU and config 4's fixed total sharded over N > 1 GPUs."""
+    import json
+    bench = importlib.import_module("bench")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    pa, off, synth, log2n, elites, scaling, label, cfg = bench.resolve_workload(None, 1)
+    assert (pa + off, synth, log2n, cfg, scaling) == (65536, "2op", 10, 2, "weak") and "configs[2]" in label
+    pa, off, synth, log2n, elites, scaling, label, cfg = bench.resolve_workload(None, 8)
+    assert (pa + off, synth, log2n, cfg, scaling) == (131072, "2op", 10, 4, "strong") and "configs[4]" in label
+    assert (pa + off) * 8 == 1048576
+    pa, off, synth, log2n, elites, scaling, label, cfg = bench.resolve_workload(3, 8)
+    assert (pa + off, synth, log2n, elites) == (32768, "4op_series", 12, 16) and "configs[3]" in label
+    pa, off, *_ = bench.resolve_workload(3, 1)
+    assert pa + off == 262144
+    pa, off, *_ = bench.resolve_workload(3, 1, shard_of=8)
+    assert pa + off == 32768
+    # the preset texts are BASELINE.json's own strings up to typography
+    for i, c in bench.BASELINE_CONFIGS.items():
+        norm = lambda t: t.replace("×", "x").replace("—", "-")
+        assert norm(base[i]) == c["text"], (base[i], c["text"])
+    # a population must stay a multiple of the recombination block
+    for g in (1, 2, 4, 8):
+        for cfg in (2, 3, 4):
+            pa, off, *_ = bench.resolve_workload(cfg, g)
+            assert pa % 32 == 0 and off % 32 == 0

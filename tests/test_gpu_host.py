@@ -24,6 +24,11 @@ def test_evolutionary_strategy_hip_through_base_class(tmp_path):
     assert r["chunks"] == 2
     assert r["csv_header"].startswith("Test_Name,Total_Time,Average_Time,Max_Time,Min_Time,Max_Difference,Average_Difference")
     assert r["csv_has_total"] and r["csv_rows"] >= 4
+    # per-launch rows: 2 chunks x 40 generations of the fused loop = 80 sort launches behind the averages
+    assert r["sort_total_ms"] > 0 and abs(r["sort_avg_ms"] * 80 - r["sort_total_ms"]) < 0.02 * r["sort_total_ms"]
+    # un-instrumented mode (isBenchmarking false): no hipEvents, no stage rows, only the total + a rate
+    assert r["quiet_stage_rows"] == 0 and r["quiet_rows"] == 1 and r["quiet_has_total"]
+    assert r["quiet_candidates_per_s"] > 0
     # 40 generations of 8192 candidates: the CPU oracle reaches 3.3e-9 on chunk 0 and the local
     # optimum 0.0258 on chunk 1 with this seed; the best of a random population is ~0.1-0.3
     assert r["host_fitness_chunk0"] < 1e-6

@@ -383,41 +383,66 @@ def test_config2_trajectory_per_generation_parity(pkg, O):
     es.close()
 
 
-def test_full_size_properties_config3(pkg, O):
-    """BASELINE config 3 (P=65536, 2-op, N=1024): size-independent properties."""
-    es, _ = make_pair(pkg, O, 16384, 49152, 0, 10)
-    tgt, tv = target_audio(O, 0, es.N)
-    es.set_target_audio(tgt)
-    es.init_population(0)
+def full_size_properties(pkg, O, parents, offspring, kind, log2n):
+    """Size-independent properties of one island at a BASELINE shard size: the fused loop equals the
+    stage-separated one bit for bit, the result is sorted, sorting is a permutation (checksum of
+    checksums), a planted optimum comes out first, 64 random rows match the CPU oracle."""
+    es, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    twin, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    tgt, tv = target_audio(O, kind, es.N)
+    for e in (es, twin):
+        e.set_target_audio(tgt)
+        e.init_population(0)
     es.execute_generations(2)
+    twin.execute_generation(); twin.execute_generation()
     v, s, f = es.read_population()
+    for x, y in zip((v, s, f), twin.read_population()):
+        assert np.array_equal(x, y), "fused loop differs from the stage-separated one"
+    twin.close()
     assert np.all(np.diff(f) >= 0), "population not sorted by fitness"
     assert np.all(np.isfinite(f)) and f[0] >= 0
     # one more generation staged, with a planted perfect individual: it must come out first
     es.recombine(); es.mutate()
     v, s, _ = es.read_population()
-    v[12345] = tv
+    plant = es.P // 2 + 1234
+    v[plant] = tv
     es.write_population(v, s, None)
     es.synthesise(); es.window(); es.fft(); es.fitness()
     fu = es.read_fitness()
     es.sort(); es.rotate()
     v2, s2, f2 = es.read_population()
     atol = fit_atol(O, tgt)
-    assert f2[0] <= atol and np.array_equal(v2[0], v[12345])
+    assert f2[0] <= atol and np.array_equal(v2[0], v[plant])
     # sorted output is a permutation of the input rows (checksum of checksums)
     assert np.array_equal(np.sort(fu), f2)
-    key_in = np.sort(v.astype(np.float64) @ np.array([1.0, 3.0, 7.0, 11.0]))
-    key_out = np.sort(v2.astype(np.float64) @ np.array([1.0, 3.0, 7.0, 11.0]))
-    assert np.array_equal(key_in, key_out)
+    w = np.array([1.0, 3.0, 7.0, 11.0, 13.0, 17.0, 19.0, 23.0, 29.0, 31.0, 37.0, 41.0])[: es.D]
+    assert np.array_equal(np.sort(v.astype(np.float64) @ w), np.sort(v2.astype(np.float64) @ w))
+    assert np.array_equal(np.sort(s.astype(np.float64) @ w), np.sort(s2.astype(np.float64) @ w))
     # spot-check 64 random rows of the full-size evaluation against the oracle
     rng = np.random.default_rng(5)
     rows = rng.choice(es.P, 64, replace=False)
     tgt_mag = O.spectrum(tgt)
     for r in rows:
-        a = O.synth(0, v[r], [0.0] * 4, PMAX[0], es.N)
+        a = O.synth(kind, v[r], [0.0] * es.D, PMAX[kind], es.N)
         want = O.fitness(O.spectrum(a), tgt_mag)
-        assert abs(fu[r] - want) <= FIT_RTOL * want + atol
+        assert abs(fu[r] - want) <= FIT_RTOL * want + atol, f"row {r}: {fu[r]} vs {want}"
     es.close()
+
+
+def test_full_size_properties_config2(pkg, O):
+    """BASELINE configs[2]: P = 65536 (16384 + 49152), 2-op, N = 1024, one GPU."""
+    full_size_properties(pkg, O, 16384, 49152, 0, 10)
+
+
+def test_full_size_properties_config3_shard(pkg, O):
+    """BASELINE configs[3], the per-GPU shard of the 8-GPU run: P = 32768 (8192 + 24576), 4-op series,
+    N = 4096 - the regime where k_synth<3,2> is cut into two wavefronts and the transform is k_fft_wg<12>."""
+    full_size_properties(pkg, O, 8192, 24576, 3, 12)
+
+
+def test_full_size_properties_config4_shard(pkg, O):
+    """BASELINE configs[4], the per-GPU shard of the 8-GPU run: P = 131072 (32768 + 98304), 2-op, N = 1024."""
+    full_size_properties(pkg, O, 32768, 98304, 0, 10)
 
 
 def test_island_rows_roundtrip(pkg, O):
