@@ -67,7 +67,21 @@ enum sots_stage {
     SOTS_STAGE_FUSED_VARIATION = 9, /* recombine + mutate */
     SOTS_STAGE_FUSED_SYNTH = 10,    /* synthesise */
     SOTS_STAGE_FUSED_SPECTRAL = 11, /* window + FFT + fitness */
-    SOTS_STAGE_COUNT = 12
+    SOTS_STAGE_SORT_TAIL = 12,      /* the rest of the order after a selection, produced when it is read */
+    SOTS_STAGE_COUNT = 13
+};
+
+/* What sortPopulation delivers inside sots_execute_generations (and sots_stage_select).
+ * The next generation's recombinePopulation reads whole parent blocks only (ocl_program.cl:99-112),
+ * i.e. rows 0..S-1 of the sorted half, S = max(numParents, max(1, numParents/workgroupSize)*workgroupSize). */
+enum sots_sort_mode {
+    SOTS_SORT_LAZY_TAIL = 0, /* default: each generation places rows 0..S-1, in order and bit-identical to the full
+                              * sort; rows S..P-1 are produced, from the still intact unsorted half, by the first
+                              * call that looks at them (read/write population, any sots_stage_*, packing more
+                              * than S elites).  A population too small or with S > P/2 is sorted in full. */
+    SOTS_SORT_FULL = 1,      /* the reference's behaviour: every generation sorts all P rows
+                              * (ocl_program.cl:664-711, Evolutionary_Strategy.hpp:108-124) */
+    SOTS_SORT_TOP_ONLY = 2   /* like 0 but rows S..P-1 are never produced (their content is unspecified) */
 };
 
 /* Replaces Evolutionary_Strategy_OpenCL_Arguments
@@ -136,17 +150,23 @@ int sots_stage_window(sots_ctx *ctx);
 int sots_stage_fft(sots_ctx *ctx);
 int sots_stage_fitness(sots_ctx *ctx);
 int sots_stage_sort(sots_ctx *ctx);
+/* the fused loop's sortPopulation as a stage: rows 0..S-1 only (enum sots_sort_mode); must be followed by
+ * sots_stage_rotate.  Falls back to sots_stage_sort where the selection does not apply. */
+int sots_stage_select(sots_ctx *ctx);
 int sots_stage_rotate(sots_ctx *ctx);
 
 /* stage-separated generation: the eight stages above in reference order */
 int sots_execute_generation(sots_ctx *ctx);
 /* n generations of the fused loop (recombine+mutate | synthesise | window+FFT+fitness |
- * sort | rotate); bit-identical population results to n x sots_execute_generation.
+ * sort | rotate); bit-identical population results to n x sots_execute_generation
+ * (sortPopulation places the rows the next generation reads and leaves the rest of the order to
+ * the first reader, enum sots_sort_mode).
  * The window is applied as the FFT kernel loads a row, so afterwards the audio buffer holds
  * the UN-windowed synthesis and the spectrum buffer is untouched.
  * (executeAllGenerations, ...OpenCL.hpp:542-547) */
 int sots_execute_generations(sots_ctx *ctx, uint32_t n);
 
+int sots_set_sort_mode(sots_ctx *ctx, uint32_t mode); /* enum sots_sort_mode */
 int sots_get_generation(const sots_ctx *ctx, uint32_t *generation);
 int sots_set_generation(sots_ctx *ctx, uint32_t generation);
 

@@ -24,13 +24,14 @@ SYNTH_NAMES = {"2op": SYNTH_2OP, "3op_series": SYNTH_3OP_SERIES,
 
 (STAGE_INIT, STAGE_RECOMBINE, STAGE_MUTATE, STAGE_SYNTHESISE, STAGE_WINDOW, STAGE_FFT,
  STAGE_FITNESS, STAGE_SORT, STAGE_ROTATE, STAGE_FUSED_VARIATION, STAGE_FUSED_SYNTH,
- STAGE_FUSED_SPECTRAL, STAGE_COUNT) = range(13)
+ STAGE_FUSED_SPECTRAL, STAGE_SORT_TAIL, STAGE_COUNT) = range(14)
+SORT_LAZY_TAIL, SORT_FULL, SORT_TOP_ONLY = 0, 1, 2
 
 # the reference's Benchmarker timer names, Evolutionary_Strategy_OpenCL.hpp:117
 STAGE_NAMES = ["initPopulation", "recombinePopulation", "mutatePopulation", "synthesisePopulation",
                "applyWindowPopulation", "hipFFT", "fitnessPopulation", "sortPopulation",
                "rotatePopulation", "fused:recombine+mutate", "fused:synthesise+window",
-               "fused:FFT+fitness"]
+               "fused:FFT+fitness", "sortPopulation:tail"]
 
 EXPORTS = [
     "sots_create", "sots_destroy", "sots_last_error", "sots_set_stream", "sots_synchronize",
@@ -38,7 +39,8 @@ EXPORTS = [
     "sots_write_population", "sots_read_population", "sots_read_population_other",
     "sots_write_synth", "sots_read_synth",
     "sots_stage_recombine", "sots_stage_mutate", "sots_stage_synthesise", "sots_stage_window",
-    "sots_stage_fft", "sots_stage_fitness", "sots_stage_sort", "sots_stage_rotate",
+    "sots_stage_fft", "sots_stage_fitness", "sots_stage_sort", "sots_stage_select", "sots_stage_rotate",
+    "sots_set_sort_mode",
     "sots_execute_generation", "sots_execute_generations", "sots_get_generation",
     "sots_set_generation", "sots_timing_enable", "sots_timing_reset", "sots_stage_time_ms",
     "sots_stage_launch_times_ms",
@@ -102,7 +104,8 @@ def load():
         getattr(L, name).argtypes = [vp, vp, sz, vp, sz, vp, sz]
     L.sots_write_synth.argtypes = [vp, vp, sz, vp, sz]
     L.sots_read_synth.argtypes = [vp, vp, sz, vp, sz, vp, sz]
-    for name in ("recombine", "mutate", "synthesise", "window", "fft", "fitness", "sort", "rotate"):
+    L.sots_set_sort_mode.argtypes = [vp, u32]
+    for name in ("recombine", "mutate", "synthesise", "window", "fft", "fitness", "sort", "select", "rotate"):
         getattr(L, "sots_stage_" + name).argtypes = [vp]
     L.sots_execute_generation.argtypes = [vp]
     L.sots_execute_generations.argtypes = [vp, u32]
@@ -269,8 +272,14 @@ class HipES:
     def sort(self):
         self._check(self.L.sots_stage_sort(self._h))
 
+    def select(self):
+        self._check(self.L.sots_stage_select(self._h))
+
     def rotate(self):
         self._check(self.L.sots_stage_rotate(self._h))
+
+    def set_sort_mode(self, mode):
+        self._check(self.L.sots_set_sort_mode(self._h, mode))
 
     def execute_generation(self):
         self._check(self.L.sots_execute_generation(self._h))

@@ -53,6 +53,11 @@ struct sots_ctx {
     void *sort_scratch = nullptr;
     uint32_t rows_capacity = 0;
     OccCache occ{};
+    // selection state: after the fused loop's partial sort only rows [0, tail_first) of the current half
+    // are in place; the unsorted half it came from is intact until the next generation starts
+    uint32_t sort_mode = SOTS_SORT_LAZY_TAIL;
+    bool tail_pending = false;
+    uint32_t tail_first = 0;
     // experiment switches; fixed in the shipped library, settable from the environment only in a
     // -DSOTS_EXPERIMENT build (tools/exp_*.sh)
     bool allow_cut = true;
@@ -211,6 +216,35 @@ uint32_t breeding_rows(const sots_ctx *ctx)
     return npb * block;
 }
 
+// rows the selection must deliver in order: what recombination reads, and never fewer than the parents
+uint32_t selected_rows(const sots_ctx *ctx)
+{
+    const uint32_t b = breeding_rows(ctx);
+    return b > ctx->cfg.num_parents ? b : ctx->cfg.num_parents;
+}
+
+// Produces the rows the selection left out: the full sort of the (still intact) unsorted half, writing
+// only rows >= tail_first of the current half (the rows in front are in place, immigrants included).
+int complete_tail(sots_ctx *ctx)
+{
+    if (!ctx->tail_pending) return SOTS_OK;
+    if (ctx->sort_mode == SOTS_SORT_TOP_ONLY) return SOTS_OK; // the caller asked for the selected rows only
+    SOTS_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t dst = ctx->rot, src = ctx->rot ^ 1u, first = ctx->tail_first;
+    if (first == 0) { // sots_stage_select without its sots_stage_rotate yet: the selected rows are in the other half
+        dst = ctx->rot ^ 1u;
+        src = ctx->rot;
+        first = selected_rows(ctx);
+    }
+    {
+        StageScope t(ctx, SOTS_STAGE_SORT_TAIL);
+        SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
+                                  ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D, first));
+    }
+    ctx->tail_pending = false;
+    return SOTS_OK;
+}
+
 int require_target(sots_ctx *ctx)
 {
     if (!ctx->target_set)
@@ -321,7 +355,7 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     CREATE_HIP(hipMalloc((void **)&ctx->wavetable, (size_t)SOTS_WAVETABLE_SIZE * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&ctx->window, (size_t)ctx->N * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&ctx->twiddle, (size_t)ctx->N * sizeof(float2)));
-    CREATE_HIP(hipMalloc((void **)&ctx->keys, (size_t)ctx->n_pad * sizeof(uint64_t)));
+    CREATE_HIP(hipMalloc((void **)&ctx->keys, sort_keys_bytes(ctx->P)));
     CREATE_HIP(hipMalloc(&ctx->sort_scratch, sort_scratch_bytes(ctx->P)));
     CREATE_HIP(hipMemsetAsync(ctx->values, 0, pd_bytes, ctx->stream));
     CREATE_HIP(hipMemsetAsync(ctx->steps, 0, pd_bytes, ctx->stream));
@@ -429,6 +463,7 @@ int sots_write_population(sots_ctx *ctx, const float *values, size_t values_byte
                           size_t steps_bytes, const float *fitness, size_t fitness_bytes)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     return copy_population(ctx, ctx->rot, true, (void *)values, values_bytes, (void *)steps, steps_bytes,
                            (void *)fitness, fitness_bytes);
 }
@@ -437,6 +472,7 @@ int sots_read_population(sots_ctx *ctx, float *values, size_t values_bytes, floa
                          float *fitness, size_t fitness_bytes)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     return copy_population(ctx, ctx->rot, false, values, values_bytes, steps, steps_bytes, fitness, fitness_bytes);
 }
 
@@ -487,6 +523,7 @@ int sots_read_synth(sots_ctx *ctx, float *audio, size_t audio_bytes, float *spec
 int sots_stage_recombine(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
     {
@@ -500,6 +537,7 @@ int sots_stage_recombine(sots_ctx *ctx)
 int sots_stage_mutate(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_MUTATE);
@@ -511,6 +549,7 @@ int sots_stage_mutate(sots_ctx *ctx)
 int sots_stage_synthesise(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_SYNTHESISE);
@@ -523,6 +562,7 @@ int sots_stage_synthesise(sots_ctx *ctx)
 int sots_stage_window(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_WINDOW);
@@ -534,6 +574,7 @@ int sots_stage_window(sots_ctx *ctx)
 int sots_stage_fft(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_FFT);
@@ -545,6 +586,7 @@ int sots_stage_fft(sots_ctx *ctx)
 int sots_stage_fitness(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     if (int rc = require_target(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
@@ -558,6 +600,7 @@ int sots_stage_fitness(sots_ctx *ctx)
 int sots_stage_sort(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
     {
@@ -568,12 +611,34 @@ int sots_stage_sort(sots_ctx *ctx)
     return maybe_drain(ctx);
 }
 
+int sots_stage_select(sots_ctx *ctx)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = bind_device(ctx)) return rc;
+    const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u, need = selected_rows(ctx);
+    if (ctx->sort_mode == SOTS_SORT_FULL || !select_applies(ctx->P, need)) return sots_stage_sort(ctx);
+    {
+        StageScope t(ctx, SOTS_STAGE_SORT);
+        SOTS_HIP(ctx, launch_select(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
+                                    ctx->fit(dst), ctx->keys, ctx->P, ctx->D, need, ctx->num_cus));
+    }
+    ctx->tail_pending = true; // completed from the current (unsorted) half once sots_stage_rotate has flipped
+    ctx->tail_first = 0;      // marks "selected into the other half, not rotated yet"
+    return maybe_drain(ctx);
+}
+
 int sots_stage_rotate(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
     if (int rc = bind_device(ctx)) return rc;
     // rotationIndex_ flip, ...OpenCL.hpp:486; a kernel argument here, so no transfer
     StageScope t(ctx, SOTS_STAGE_ROTATE);
+    if (ctx->tail_pending && ctx->tail_first == 0) { // sots_stage_select just ran: its rows are in the OTHER half
+        ctx->tail_first = selected_rows(ctx);
+    } else if (ctx->tail_pending) {
+        if (int rc = complete_tail(ctx)) return rc;
+    }
     ctx->rot ^= 1u;
     ctx->generation += 1;
     return SOTS_OK;
@@ -599,7 +664,14 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
     SOTS_REQUIRE_CTX(ctx);
     if (int rc = require_target(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
+    if (ctx->tail_pending && ctx->tail_first == 0)
+        return fail(ctx, SOTS_ERR_STATE, "sots_stage_select must be followed by sots_stage_rotate");
+    const uint32_t need = selected_rows(ctx);
+    const bool select = ctx->sort_mode != SOTS_SORT_FULL && select_applies(ctx->P, need);
     for (uint32_t g = 0; g < n; ++g) {
+        // the variation below overwrites the unsorted half a pending tail would be completed from; nobody has
+        // asked for those rows, so they are dropped
+        ctx->tail_pending = false;
         uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
         // Large populations of 4-gene individuals make their individuals inside the synthesis kernel
         // (one launch less, 151 vs 157 us per generation at P = 65536); with few wavefronts per CU or
@@ -630,13 +702,30 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         dst = ctx->rot ^ 1u;
         {
             StageScope t(ctx, SOTS_STAGE_SORT);
-            SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
-                                      ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D));
+            if (select) {
+                // the rows recombination reads, in order; the rest of the order is produced on demand
+                SOTS_HIP(ctx, launch_select(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst),
+                                            ctx->stp(dst), ctx->fit(dst), ctx->keys, ctx->P, ctx->D, need, ctx->num_cus));
+            } else {
+                SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
+                                          ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D));
+            }
         }
         ctx->rot = dst;
+        ctx->tail_pending = select;
+        ctx->tail_first = need;
         ctx->generation += 1;
         if (int rc = maybe_drain(ctx)) return rc;
     }
+    return SOTS_OK;
+}
+
+int sots_set_sort_mode(sots_ctx *ctx, uint32_t mode)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (mode > SOTS_SORT_TOP_ONLY) return fail(ctx, SOTS_ERR_INVALID, "unknown sort mode %u", mode);
+    if (int rc = complete_tail(ctx)) return rc;
+    ctx->sort_mode = mode;
     return SOTS_OK;
 }
 
@@ -706,6 +795,8 @@ int sots_pack_elites_device(sots_ctx *ctx, void *device_rows, uint32_t n_rows)
 {
     SOTS_REQUIRE_CTX(ctx);
     if (!device_rows || n_rows > ctx->P) return fail(ctx, SOTS_ERR_INVALID, "pack_elites: bad rows/n_rows %u", n_rows);
+    if (ctx->tail_pending && n_rows > ctx->tail_first)
+        if (int rc = complete_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     SOTS_HIP(ctx, launch_pack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
                                    (float *)device_rows, 0, n_rows, ctx->D));

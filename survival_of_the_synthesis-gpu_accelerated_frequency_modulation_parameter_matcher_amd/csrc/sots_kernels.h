@@ -87,11 +87,19 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
                               float inv_n, float inv_wf, uint32_t num_cus, OccCache *occ);
 
 // ---- selection ----
-// keys: P_pad 64-bit words (P_pad = next power of two >= P); scratch: sort_scratch_bytes(P) bytes
+// keys: sort_keys_bytes(P) bytes; scratch: sort_scratch_bytes(P) bytes.  Rows that would land in front of
+// `first_row` are not written (the selection below has placed them already).
 size_t sort_scratch_bytes(uint32_t p);
+size_t sort_keys_bytes(uint32_t p);
 hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
                        float *vout, float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p,
-                       uint32_t d);
+                       uint32_t d, uint32_t first_row = 0);
+// the best `need` rows in order into rows 0..need-1 of the out arrays, other rows untouched; only
+// where select_applies() (otherwise hipErrorInvalidValue)
+bool select_applies(uint32_t p, uint32_t need);
+hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, const float *fin, float *vout,
+                         float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d, uint32_t need,
+                         uint32_t num_cus);
 
 // ---- island exchange ----
 hipError_t launch_pack_rows(hipStream_t st, const float *values, const float *steps, const float *fitness,

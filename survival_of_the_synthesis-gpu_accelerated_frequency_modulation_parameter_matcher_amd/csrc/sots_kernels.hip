@@ -1405,7 +1405,8 @@ __global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64
                                                                     const float *__restrict__ fin,
                                                                     float *__restrict__ vout, float *__restrict__ sout,
                                                                     float *__restrict__ fout, uint32_t n_pad,
-                                                                    uint32_t groups, uint32_t p_len, uint32_t d)
+                                                                    uint32_t groups, uint32_t p_len, uint32_t d,
+                                                                    uint32_t first_row)
 {
     constexpr uint32_t kSlots = 64;
     __shared__ uint32_t part[4][kSlots];
@@ -1423,6 +1424,7 @@ __global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64
         const uint32_t src = src_row[jj];
         if (src >= p_len) continue;
         const uint32_t dst = part[0][jj] + part[1][jj] + part[2][jj] + part[3][jj];
+        if (dst < first_row) continue; // rows the selection kernels have already placed
         if (c < d) vout[(size_t)dst * d + c] = vin[(size_t)src * d + c];
         else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = sin[(size_t)src * d + (c - d)];
         else fout[dst] = fin[src];
@@ -1435,16 +1437,269 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint64_t *__restrict_
                                                      const float *__restrict__ sin,
                                                      const float *__restrict__ fin, float *__restrict__ vout,
                                                      float *__restrict__ sout, float *__restrict__ fout,
-                                                     uint32_t p_len, uint32_t d)
+                                                     uint32_t p_len, uint32_t d, uint32_t first_row)
 {
     const uint32_t w = 2 * d + 1;
     const uint32_t total = p_len * w;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x + first_row * w; e < total; e += gridDim.x * blockDim.x) {
         const uint32_t r = e / w, c = e - r * w;
         const uint32_t src = (uint32_t)keys[r];
         if (c < d) vout[r * d + c] = vin[src * d + c];
         else if (c < 2 * d) sout[r * d + (c - d)] = sin[src * d + (c - d)];
         else fout[r] = fin[src];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Selection for the fused generation loop: the best `need` rows IN ORDER and nothing else.
+// The next recombination reads whole parent blocks only (recombine_source above,
+// ocl_program.cl:99-112), so inside sots_execute_generations the order of the other rows is
+// never looked at; the full order is produced (by launch_sort, from the untouched unsorted half)
+// when somebody reads the population.  Rows 0..need-1 are bit-identical to the full sort's.
+//
+// Two launches.  k_sel_tiles sorts tiles of 1024 (fitness bits, index) keys: one key per lane,
+// 16 wavefronts sort 64 keys each in registers (bitonic network over lane exchanges, no LDS
+// traffic, no barrier), then every key's place in the tile is its lane plus its lower bound in
+// the other 15 runs.  It writes the sorted fitness bits and indices as two u32 arrays and, per
+// tile, the four keys at positions 255, 511, 767, 1023 ("samples").
+// k_sel_rank_scatter (one workgroup per CU) finds v* = the ceil(need/256)-th smallest sample:
+// at least need keys are <= v*, and every key <= v* lies in its tile's first
+// 256 * (samples_t <= v*) + 256 positions.  Only those prefixes (need + 256 * tiles keys when
+// there are no ties: 128 KiB at P = 65536) are staged in LDS as 4-byte fitness bits; a staged key's
+// rank is the sum of its lower bounds in every staged prefix, and keys whose rank is below `need`
+// move their rows.  Tiles are contiguous index ranges, so "equal fitness, lower index first" needs
+// no index in LDS: against an EARLIER tile an equal key counts (<=), against a LATER one it does
+// not (<).  Keys above v* get ranks >= need (every key <= v* is staged and there are >= need of
+// them), so no check can fail and there is no fallback path; prefixes that exceed the LDS are staged
+// in several passes.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t kSelTile = 1024, kSelSamples = 4, kSelQuantum = kSelTile / kSelSamples;
+constexpr uint32_t kSelThreads = 512, kSelLanesPerKey = 8, kSelKeysPerRound = kSelThreads / kSelLanesPerKey;
+constexpr uint32_t kSelCap = 34816;                 // staged keys per pass: 136 KiB of LDS
+constexpr uint32_t kSelWindow = kSelCap - kSelTile; // a tile whose prefix STARTS inside the window fits whole
+constexpr uint32_t kSelMaxTiles = 512, kSelMaxOwn = 512;
+
+// order-preserving bits of a fitness: every number below NaN (0xFFFFFFFE), NaN below the padding key
+__device__ __forceinline__ uint32_t order_bits(float f)
+{
+    if (f != f) return 0xFFFFFFFEu;
+    const uint32_t u = __float_as_uint(f == 0.0f ? 0.0f : f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// lower bound in a sorted run of 64: number of entries < thr (LE: <= thr)
+template <bool LE>
+__device__ __forceinline__ uint32_t run_lower_bound(const uint32_t *__restrict__ r, uint32_t thr)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t step = 32; step >= 1; step >>= 1) {
+        const uint32_t v = r[pos + step - 1];
+        pos += (LE ? v <= thr : v < thr) ? step : 0u;
+    }
+    const uint32_t v = r[pos];
+    return pos + ((LE ? v <= thr : v < thr) ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict__ fitness, uint32_t *__restrict__ kbits,
+                                                         uint32_t *__restrict__ kidx, uint32_t *__restrict__ samples,
+                                                         uint32_t p_len)
+{
+    __shared__ uint32_t runs[kSelTile];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const uint32_t g = blockIdx.x * kSelTile + tid;
+    uint32_t b = g < p_len ? order_bits(fitness[g]) : 0xFFFFFFFFu, i = g; // padding keys sort last, by index
+#pragma unroll
+    for (uint32_t k = 2; k <= (uint32_t)kWave; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t pb = (uint32_t)__shfl_xor((int)b, (int)j), pi = (uint32_t)__shfl_xor((int)i, (int)j);
+            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+            const bool mine_less = b < pb || (b == pb && i < pi);
+            if (keep_min != mine_less) {
+                b = pb;
+                i = pi;
+            }
+        }
+    }
+    runs[tid] = b;
+    __syncthreads();
+    // place in the tile = lane + lower bounds in the other runs; a run of an earlier wavefront holds lower
+    // indices, so its equal keys come first (<=), a later run's do not (<)
+    uint32_t rank = lane;
+#pragma unroll
+    for (uint32_t w = 0; w < kSelTile / kWave; ++w) {
+        if (w < wave) rank += run_lower_bound<true>(runs + w * kWave, b);
+        else if (w > wave) rank += run_lower_bound<false>(runs + w * kWave, b);
+    }
+    const size_t o = (size_t)blockIdx.x * kSelTile + rank;
+    kbits[o] = b;
+    kidx[o] = i;
+    if ((rank & (kSelQuantum - 1)) == kSelQuantum - 1) samples[blockIdx.x * kSelSamples + rank / kSelQuantum] = b;
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t *__restrict__ kbits,
+                                                                  const uint32_t *__restrict__ kidx,
+                                                                  const uint32_t *__restrict__ samples,
+                                                                  const float *__restrict__ vin,
+                                                                  const float *__restrict__ sin,
+                                                                  const float *__restrict__ fin,
+                                                                  float *__restrict__ vout, float *__restrict__ sout,
+                                                                  float *__restrict__ fout, uint32_t tiles, uint32_t need,
+                                                                  uint32_t p_len, uint32_t d)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t staged[kSelCap];
+    __shared__ __attribute__((aligned(16))) uint32_t smp[kSelMaxTiles * kSelSamples];
+    __shared__ uint32_t off[kSelMaxTiles + 1]; // first staged position of each tile, all passes concatenated
+    __shared__ uint32_t own_bits[kSelMaxOwn], own_tile[kSelMaxOwn], own_pos[kSelMaxOwn], own_rank[kSelMaxOwn];
+    __shared__ uint32_t wave_tot[kSelThreads / kWave];
+    __shared__ uint32_t vstar_s;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const uint32_t ns = tiles * kSelSamples;
+
+    // ---- v* = the k-th smallest sample, k = ceil(need / 256) --------------------------------------
+    for (uint32_t e = tid; e < ns; e += kSelThreads) smp[e] = samples[e];
+    if (tid == 0) vstar_s = 0u;
+    __syncthreads();
+    const uint32_t kth = (need + kSelQuantum - 1) / kSelQuantum;
+    if (kth > ns) {
+        if (tid == 0) vstar_s = 0xFFFFFFFFu; // more rows wanted than samples can vouch for: stage everything
+    } else {
+        // two lanes per sample, each counts the samples below it in one half of the list; the k-th
+        // smallest VALUE is the largest sample with at most k-1 samples below it
+        const uint4 *__restrict__ s4 = reinterpret_cast<const uint4 *>(smp);
+        const uint32_t half = tid & 1u, q4 = ns / 8u; // uint4 groups per half (ns is a multiple of 16)
+        for (uint32_t sidx = tid >> 1; sidx < ns; sidx += kSelThreads / 2) {
+            const uint32_t v = smp[sidx];
+            uint32_t below = 0;
+            for (uint32_t e = half * q4; e < (half + 1u) * q4; ++e) {
+                const uint4 c = s4[e];
+                below += (c.x < v) + (c.y < v) + (c.z < v) + (c.w < v);
+            }
+            below += (uint32_t)__shfl_xor((int)below, 1);
+            if (half == 0 && below < kth) atomicMax(&vstar_s, v);
+        }
+    }
+    __syncthreads();
+    const uint32_t vstar = vstar_s;
+
+    // ---- staged prefix of every tile, exclusive scan -> off[] ------------------------------------
+    {
+        uint32_t len = 0;
+        if (tid < tiles) {
+            uint32_t m = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kSelSamples; ++j) m += smp[tid * kSelSamples + j] <= vstar ? 1u : 0u;
+            len = m >= kSelSamples ? kSelTile : (m + 1u) * kSelQuantum;
+        }
+        uint32_t incl = len;
+#pragma unroll
+        for (uint32_t sh = 1; sh < (uint32_t)kWave; sh <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, (int)sh);
+            if (lane >= sh) incl += up;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+        if (tid < tiles) off[tid + 1] = before + incl;
+        if (tid == 0) off[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t total = off[tiles];
+
+    // ---- this workgroup's keys: an equal share of the staged positions ---------------------------
+    const uint32_t share = (total + gridDim.x - 1) / gridDim.x; // <= kSelMaxOwn by the launcher's grid
+    for (uint32_t slot = tid; slot < share; slot += kSelThreads) {
+        const uint32_t g = blockIdx.x * share + slot;
+        uint32_t t = 0xFFFFFFFFu, pos = 0, bits = 0;
+        if (g < total) {
+            uint32_t lo = 0, len = tiles; // last tile with off[tile] <= g
+            while (len > 1) {
+                const uint32_t h = len >> 1;
+                lo += off[lo + h] <= g ? h : 0u;
+                len -= h;
+            }
+            pos = g - off[lo];
+            bits = kbits[(size_t)lo * kSelTile + pos];
+            if (bits != 0xFFFFFFFFu) t = lo; // padding keys move nothing
+        }
+        own_tile[slot] = t;
+        own_pos[slot] = pos;
+        own_bits[slot] = bits;
+        own_rank[slot] = 0;
+    }
+
+    // ---- passes over the staged prefixes ---------------------------------------------------------
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const uint32_t sub = tid & (kSelLanesPerKey - 1);
+    const uint32_t passes = off[tiles - 1] / kSelWindow + 1;
+    uint32_t ta = 0;
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        const uint32_t w0 = pass * kSelWindow;
+        uint32_t tb = 0; // first tile that starts at or beyond the end of this window: tiles [ta, tb) are staged
+        for (uint32_t len = tiles; len > 0;) {
+            const uint32_t h = len >> 1;
+            if (off[tb + h] < w0 + kSelWindow) {
+                tb += h + 1;
+                len -= h + 1;
+            } else {
+                len = h;
+            }
+        }
+        __syncthreads(); // the previous pass's searches are done (and own_* / off[] are in place)
+        for (uint32_t tt = ta + wave; tt < tb; tt += kSelThreads / kWave) {
+            const uint32_t o = off[tt] - w0, n = off[tt + 1] - off[tt];
+            const uint32_t *__restrict__ src = kbits + (size_t)tt * kSelTile;
+            for (uint32_t e = 0; e < n; e += 4 * kWave) // n is a multiple of 256: whole wavefront instructions
+                __builtin_amdgcn_global_load_lds(src + e + 4 * lane, (lds_ptr_t)(staged + o + e), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): this wavefront's copies have landed
+        __syncthreads();
+        for (uint32_t r0 = 0; r0 < share; r0 += kSelKeysPerRound) {
+            const uint32_t slot = r0 + tid / kSelLanesPerKey;
+            const uint32_t t_own = slot < share ? own_tile[slot] : 0xFFFFFFFFu;
+            uint32_t count = 0;
+            if (t_own != 0xFFFFFFFFu) {
+                const uint32_t xb = own_bits[slot], pos_own = own_pos[slot];
+                for (uint32_t tt = ta + sub; tt < tb; tt += kSelLanesPerKey) {
+                    const uint32_t base = off[tt] - w0;
+                    uint32_t len = off[tt + 1] - off[tt];
+                    const uint32_t thr = xb + (tt < t_own ? 1u : 0u); // xb <= 0xFFFFFFFE: no overflow
+                    uint32_t lo = 0;
+                    while (len > 1) {
+                        const uint32_t h = len >> 1;
+                        lo += staged[base + lo + h - 1] < thr ? h : 0u;
+                        len -= h;
+                    }
+                    lo += staged[base + lo] < thr ? 1u : 0u;
+                    count += tt == t_own ? pos_own : lo;
+                }
+            }
+            count = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0xB1, 0xf, 0xf, false) + count;  // quad_perm [1,0,3,2]
+            count = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x4E, 0xf, 0xf, false) + count;  // quad_perm [2,3,0,1]
+            count = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x141, 0xf, 0xf, false) + count; // row_half_mirror
+            if (sub == 0 && t_own != 0xFFFFFFFFu) own_rank[slot] += count; // one writer per slot
+        }
+        ta = tb;
+    }
+    __syncthreads();
+
+    // ---- rows of the keys that made it -----------------------------------------------------------
+    const uint32_t width = 2 * d + 1;
+    for (uint32_t r0 = 0; r0 < share; r0 += kSelKeysPerRound) {
+        const uint32_t slot = r0 + tid / kSelLanesPerKey;
+        if (slot >= share) continue;
+        const uint32_t t_own = own_tile[slot], dst = own_rank[slot];
+        if (t_own == 0xFFFFFFFFu || dst >= need) continue;
+        const uint32_t src = kidx[(size_t)t_own * kSelTile + own_pos[slot]];
+        for (uint32_t c = sub; c < width; c += kSelLanesPerKey) {
+            if (c < d) vout[(size_t)dst * d + c] = vin[(size_t)src * d + c];
+            else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = sin[(size_t)src * d + (c - d)];
+            else fout[dst] = fin[src];
+        }
     }
 }
 
@@ -1707,7 +1962,7 @@ size_t sort_scratch_bytes(uint32_t p)
 
 hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
                        float *vout, float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p,
-                       uint32_t d)
+                       uint32_t d, uint32_t first_row)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
     uint32_t tile, tiles;
@@ -1729,7 +1984,7 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
         const uint32_t runs = n_pad / kRankLdsKeys;
         k_sort_rank_pairs<1><<<dim3(runs, runs), kRankThreads, 0, st>>>(merged, partial, n_pad, kRankLdsKeys);
         k_sort_rank_scatter<<<n_pad / 64, kRankThreads, 0, st>>>(merged, partial, vin, sin, fin, vout, sout, fout,
-                                                               n_pad, runs, p, d);
+                                                               n_pad, runs, p, d, first_row);
         return hipGetLastError();
     }
     if (rank_merge) {
@@ -1742,7 +1997,7 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
         default: k_sort_rank_pairs<1><<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile); break;
         }
         k_sort_rank_scatter<<<n_pad / 64, kRankThreads, 0, st>>>(keys, partial, vin, sin, fin, vout, sout, fout,
-                                                               n_pad, groups, p, d);
+                                                               n_pad, groups, p, d, first_row);
         return hipGetLastError();
     }
     for (uint32_t k = tile << 1; k <= n_pad && k != 0; k <<= 1) {
@@ -1751,7 +2006,42 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
         k_sort_tile_merge<<<tiles, threads, 0, st>>>(keys, k, tile);
     }
     k_sort_gather<<<grid_for((uint64_t)p * (2 * d + 1), 256), 256, 0, st>>>(keys, vin, sin, fin, vout, sout,
-                                                                            fout, p, d);
+                                                                            fout, p, d, first_row);
+    return hipGetLastError();
+}
+
+// keys buffer: n_pad 64-bit keys (full sort) or n_pad fitness-bit words + n_pad indices (selection),
+// followed by the selection's per-tile samples
+size_t sort_keys_bytes(uint32_t p)
+{
+    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    return (size_t)n_pad * sizeof(uint64_t) + (size_t)kSelMaxTiles * kSelSamples * sizeof(uint32_t);
+}
+
+// The selection applies from four tiles up to kSelMaxTiles and while at most half of the rows are
+// wanted (beyond that nearly everything would be staged and the full sort is the better plan).
+bool select_applies(uint32_t p, uint32_t need)
+{
+    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    const uint32_t tiles = n_pad / kSelTile;
+    return tiles >= 4 && tiles <= kSelMaxTiles && need >= 1 && (uint64_t)need * 2 <= p;
+}
+
+hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, const float *fin, float *vout,
+                         float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d, uint32_t need,
+                         uint32_t num_cus)
+{
+    if (!select_applies(p, need)) return hipErrorInvalidValue;
+    const uint32_t n_pad = next_pow2(p);
+    const uint32_t tiles = n_pad / kSelTile;
+    uint32_t *kbits = reinterpret_cast<uint32_t *>(keys), *kidx = kbits + n_pad, *samples = kidx + n_pad;
+    k_sel_tiles<<<tiles, kSelTile, 0, st>>>(fin, kbits, kidx, samples, p);
+    // one workgroup per CU (the staging buffer takes the LDS); more only when a share of the staged
+    // positions would exceed the per-workgroup key store
+    uint32_t grid = num_cus ? num_cus : 256;
+    const uint32_t min_grid = (tiles * kSelTile + kSelMaxOwn - 1) / kSelMaxOwn;
+    if (grid < min_grid) grid = min_grid;
+    k_sel_rank_scatter<<<grid, kSelThreads, 0, st>>>(kbits, kidx, samples, vin, sin, fin, vout, sout, fout, tiles, need, p, d);
     return hipGetLastError();
 }
 

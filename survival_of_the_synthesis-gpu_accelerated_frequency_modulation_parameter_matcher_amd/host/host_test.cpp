@@ -64,6 +64,7 @@ int main(int argc, char **argv)
         es->objective.calculateFFT(audio.data(), magB.data());
         double host_fit = 0.0;
         for (uint32_t k = 0; k < n / 2; ++k) host_fit += (double)(magB[k] - magA[k]) * (magB[k] - magA[k]);
+        const size_t chunks = best.size(); // `best` lives inside *es, which is destroyed below
 
         // staged loop must give the same population as the fused loop
         auto argsStaged = args;
@@ -135,7 +136,7 @@ int main(int argc, char **argv)
                "\"chunks\": %zu, \"fused_equals_staged\": %s, \"csv_header\": \"%s\", \"csv_rows\": %d, \"csv_has_total\": %s, "
                "\"bad_config_throws\": %s, \"staged_fft_pending\": %u, \"quiet_rows\": %d, \"quiet_stage_rows\": %d, "
                "\"quiet_has_total\": %s, \"quiet_candidates_per_s\": %.6g, \"sort_total_ms\": %.9g, \"sort_avg_ms\": %.9g}\n",
-               sorted ? "true" : "false", aos_ok ? "true" : "false", f[0], host_fit, best.size(), same ? "true" : "false",
+               sorted ? "true" : "false", aos_ok ? "true" : "false", f[0], host_fit, chunks, same ? "true" : "false",
                header.c_str(), rows, has_total ? "true" : "false", threw ? "true" : "false", staged_fft_calls, quiet_rows,
                quiet_stage_rows, quiet_total ? "true" : "false", quiet_rate, total_sort_ms, avg_sort_ms);
         return 0;

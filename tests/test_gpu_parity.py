@@ -307,6 +307,108 @@ def test_sort_matches_stable_oracle(pkg, O, parents, offspring, block):
     es.close()
 
 
+def fitness_pattern(name, P, rng):
+    """Fitness vectors that stress the selection: the tiles of 1024 consecutive rows it sorts first may be
+    alike or wildly different, values may repeat across tiles, NaN / inf / signed zeros may sit anywhere."""
+    if name == "random":
+        f = rng.random(P, dtype=np.float32)
+    elif name == "ascending":           # the best rows are all in the first tiles
+        f = np.arange(P, dtype=np.float32) / P
+    elif name == "descending":          # ... in the last tiles
+        f = (P - np.arange(P, dtype=np.float32)) / P
+    elif name == "constant":            # every key ties: the order is the index order
+        f = np.full(P, 0.25, np.float32)
+    elif name == "few_values":          # massive ties across tiles
+        f = rng.integers(0, 5, P).astype(np.float32)
+    elif name == "tile_skew":           # good and bad tiles alternate, as offspring of good and bad parent blocks do
+        f = (rng.random(P, dtype=np.float32) * np.where((np.arange(P) // 1024) % 4 == 0, 0.05, 1.0)).astype(np.float32)
+    elif name == "converged":           # tiny values in a narrow band + exact zeros
+        f = (1e-12 * (1 + 1e-3 * rng.random(P))).astype(np.float32)
+        f[rng.choice(P, P // 50, replace=False)] = 0.0
+    elif name == "specials":
+        f = sort_case(P, rng)
+        f[::97] = f[5]
+        f[rng.choice(P, P // 3, replace=False)] = np.nan    # more NaN than non-selected rows can hide
+        f[rng.choice(P, 50, replace=False)] = -np.inf
+        f[rng.choice(P, 50, replace=False)] = -1.5
+    else:
+        raise ValueError(name)
+    return f
+
+
+SELECT_CASES = [
+    # parents, offspring, kind, pattern
+    (1024, 3072, 0, "random"), (2048, 6144, 1, "tile_skew"), (6000 - 6000 % 32, 18000 - 18000 % 32, 0, "random"),
+    (16384, 49152, 0, "random"), (16384, 49152, 0, "ascending"), (16384, 49152, 0, "descending"),
+    (16384, 49152, 0, "constant"), (16384, 49152, 0, "few_values"), (16384, 49152, 0, "tile_skew"),
+    (16384, 49152, 0, "converged"), (16384, 49152, 2, "specials"), (64, 65472, 0, "random"), (32768, 32768, 0, "tile_skew"),
+    (8192, 24576, 3, "tile_skew"), (32768, 98304, 0, "tile_skew"), (32768, 98304, 0, "few_values"),
+    (65536, 196608, 0, "random"), (40000, 110016, 0, "specials"),
+]
+
+
+@pytest.mark.parametrize("parents,offspring,kind,pattern", SELECT_CASES)
+def test_select_places_exactly_the_rows_recombination_reads(pkg, O, parents, offspring, kind, pattern):
+    """sots_stage_select (the fused loop's sortPopulation): rows 0..S-1 equal the stable full sort's bit for
+    bit and NOTHING else is written (sentinel rows stay); the first reader then gets the whole order."""
+    es, _ = make_pair(pkg, O, parents, offspring, kind, 9)
+    rng = np.random.default_rng(parents + len(pattern))
+    P, D = es.P, es.D
+    S = max(parents, max(1, parents // 32) * 32)
+    f = fitness_pattern(pattern, P, rng)
+    v = rng.random((P, D), dtype=np.float32)
+    s = rng.random((P, D), dtype=np.float32)
+    sentinel_v = np.full((P, D), -7.0, np.float32)
+    es.set_sort_mode(pkg.capi.SORT_TOP_ONLY)
+    es.write_population(sentinel_v, sentinel_v, np.full(P, -7.0, np.float32))  # the half the selection writes into
+    es.rotate()
+    es.write_population(v, s, f)
+    es.select(); es.rotate()
+    gv, gs, gf = es.read_population()
+    perm = O.sort_perm(f)
+    assert np.array_equal(gf[:S], f[perm][:S], equal_nan=True)
+    assert np.array_equal(gv[:S], v[perm][:S]) and np.array_equal(gs[:S], s[perm][:S])
+    assert np.all(gf[S:] == -7.0) and np.all(gv[S:] == -7.0) and np.all(gs[S:] == -7.0), "rows beyond S were written"
+    # the rest of the order on demand, from the untouched unsorted half
+    es.set_sort_mode(pkg.capi.SORT_LAZY_TAIL)
+    gv, gs, gf = es.read_population()
+    assert np.array_equal(gf, f[perm], equal_nan=True) and np.array_equal(gv, v[perm]) and np.array_equal(gs, s[perm])
+    ov, os_, of = es.read_population(other=True)
+    assert np.array_equal(ov, v) and np.array_equal(os_, s) and np.array_equal(of, f, equal_nan=True)
+    es.close()
+
+
+def test_lazy_tail_keeps_immigrants_and_full_sort_mode_matches(pkg, O):
+    """After a fused generation only the breeding rows are in place; immigrants injected into them must survive
+    the completion of the order, and SOTS_SORT_FULL (the reference's every-generation full sort) must give the
+    same populations as the default mode."""
+    a, _ = make_pair(pkg, O, 2048, 6144, 0, 10)
+    b, _ = make_pair(pkg, O, 2048, 6144, 0, 10)
+    b.set_sort_mode(pkg.capi.SORT_FULL)
+    tgt, _ = target_audio(O, 0, a.N)
+    rng = np.random.default_rng(4)
+    imm = rng.random((48, 2 * a.D + 1), dtype=np.float32)
+    for es in (a, b):
+        es.set_target_audio(tgt)
+        es.init_population(0)
+        es.timing_enable(True)
+        es.execute_generations(3)
+        es.inject_immigrants(imm)
+    assert a.stage_time_ms(pkg.capi.STAGE_SORT_TAIL)[1] == 0, "nobody has looked at the tail yet"
+    pa, pb = a.read_population(), b.read_population()
+    assert a.stage_time_ms(pkg.capi.STAGE_SORT_TAIL)[1] == 1 and b.stage_time_ms(pkg.capi.STAGE_SORT_TAIL)[1] == 0
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(pa[2][2048 - 48:2048], imm[:, 0]) and np.array_equal(pa[0][2048 - 48:2048], imm[:, 1:5])
+    assert np.all(np.diff(pa[2][2048:]) >= 0)
+    # and the runs continue identically
+    for es in (a, b):
+        es.execute_generations(2)
+    for x, y in zip(a.read_population(), b.read_population()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 # the last case is large enough (>= 192 individuals per CU, 4 genes) for the fused loop to make its
 # individuals inside the synthesis kernel, with a partly filled last tile
 @pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (3, 12, 32, 96), (2, 10, 32, 96),
