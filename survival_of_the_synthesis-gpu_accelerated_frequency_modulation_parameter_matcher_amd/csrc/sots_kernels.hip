@@ -284,8 +284,24 @@ struct StampScope {
     }
 };
 #define SOTS_STAMP_SCOPE(slot) StampScope stamp_scope_(slot)
+// phase stamps of the selection kernels: shader cycles since the workgroup started, 16 phases per workgroup,
+// kept behind the synthesis stamps (slots 8192..)
+#define SOTS_PHASE_BEGIN() const unsigned long long phase_t0_ = __builtin_amdgcn_s_memtime()
+#define SOTS_PHASE(n)                                                                                              \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 512)                                                                  \
+            g_stamps[2 * 8192 + blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime() - phase_t0_;                 \
+    } while (0)
+// absolute clock of any one lane (diagnostics of wavefront start skew inside a workgroup)
+#define SOTS_PHASE_ABS(n, cond)                                                                                   \
+    do {                                                                                                           \
+        if ((cond) && blockIdx.x < 512) g_stamps[2 * 8192 + blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
 #define SOTS_STAMP_SCOPE(slot)
+#define SOTS_PHASE_BEGIN()
+#define SOTS_PHASE(n)
+#define SOTS_PHASE_ABS(n, cond)
 #endif
 
 // ---- every voice, one lane per individual, whole-line stores through LDS -------------------
@@ -1474,70 +1490,108 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint64_t *__restrict_
 // in several passes.
 // ------------------------------------------------------------------------------------
 constexpr uint32_t kSelTile = 1024, kSelSamples = 4, kSelQuantum = kSelTile / kSelSamples;
-constexpr uint32_t kSelThreads = 512, kSelLanesPerKey = 8, kSelKeysPerRound = kSelThreads / kSelLanesPerKey;
-constexpr uint32_t kSelCap = 34816;                 // staged keys per pass: 136 KiB of LDS
-constexpr uint32_t kSelWindow = kSelCap - kSelTile; // a tile whose prefix STARTS inside the window fits whole
-constexpr uint32_t kSelMaxTiles = 512, kSelMaxOwn = 512;
+constexpr uint32_t kSelThreads = 1024, kSelLanesPerKey = 8, kSelKeysPerRound = kSelThreads / kSelLanesPerKey;
+constexpr uint32_t kSelCap = 35328;                 // staged keys per pass: 138 KiB of LDS
+constexpr uint32_t kSelSkew = 4;                    // consecutive tiles start 4 more words (16 B) off the 1 KiB grid, see below
+// a tile whose prefix STARTS inside the window fits whole, skew included (at most window / 256 tiles per pass)
+constexpr uint32_t kSelWindow = 33536;
+static_assert(kSelWindow + kSelTile + kSelSkew * (kSelWindow / kSelQuantum) <= kSelCap, "staging buffer too small");
+constexpr uint32_t kSelMinTiles = 16, kSelMaxTiles = 256, kSelMaxOwn = 512;
 
-// order-preserving bits of a fitness: every number below NaN (0xFFFFFFFE), NaN below the padding key
+// order-preserving bits of a fitness: every number (at most 0xFF800000, +inf) below NaN (0xFFFFFFFD), NaN
+// below the padding key (0xFFFFFFFE); 0xFFFFFFFF stays free so that "bits + 1" never wraps
+constexpr uint32_t kSelPadBits = 0xFFFFFFFEu;
 __device__ __forceinline__ uint32_t order_bits(float f)
 {
-    if (f != f) return 0xFFFFFFFEu;
+    if (f != f) return 0xFFFFFFFDu;
     const uint32_t u = __float_as_uint(f == 0.0f ? 0.0f : f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// lower bound in a sorted run of 64: number of entries < thr (LE: <= thr)
-template <bool LE>
-__device__ __forceinline__ uint32_t run_lower_bound(const uint32_t *__restrict__ r, uint32_t thr)
+// value of lane (lane ^ J) for J = 1, 2 (DPP quad permutes), 4, 8, 16 (ds_swizzle through the LDS crossbar,
+// no LDS memory), 32 (v_permlane32_swap)
+template <uint32_t J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
 {
-    uint32_t pos = 0;
-#pragma unroll
-    for (uint32_t step = 32; step >= 1; step >>= 1) {
-        const uint32_t v = r[pos + step - 1];
-        pos += (LE ? v <= thr : v < thr) ? step : 0u;
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); // quad_perm [2,3,0,1]
+    else if constexpr (J == 32) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32u) ? sw[0] : sw[1]; // lanes 32-63 get lane-32's value in [0], lanes 0-31 lane+32's in [1]
+    } else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (int)((J << 10) | 0x1Fu)); // bit mode: xor J, and 0x1f
+}
+
+template <uint32_t K, uint32_t J>
+__device__ __forceinline__ void bitonic_step(uint32_t &b, uint32_t &i, uint32_t lane)
+{
+    const uint32_t pb = lane_xor<J>(b), pi = lane_xor<J>(i);
+    const bool keep_min = ((lane & J) == 0) == ((lane & K) == 0);
+    const bool mine_less = b < pb || (b == pb && i < pi);
+    if (keep_min != mine_less) {
+        b = pb;
+        i = pi;
     }
-    const uint32_t v = r[pos];
-    return pos + ((LE ? v <= thr : v < thr) ? 1u : 0u);
+}
+template <uint32_t K, uint32_t J>
+__device__ __forceinline__ void bitonic_merge(uint32_t &b, uint32_t &i, uint32_t lane)
+{
+    bitonic_step<K, J>(b, i, lane);
+    if constexpr (J > 1) bitonic_merge<K, J / 2>(b, i, lane);
 }
 
 __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict__ fitness, uint32_t *__restrict__ kbits,
                                                          uint32_t *__restrict__ kidx, uint32_t *__restrict__ samples,
                                                          uint32_t p_len)
 {
+    constexpr uint32_t kRuns = kSelTile / kWave;
     __shared__ uint32_t runs[kSelTile];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const uint32_t g = blockIdx.x * kSelTile + tid;
-    uint32_t b = g < p_len ? order_bits(fitness[g]) : 0xFFFFFFFFu, i = g; // padding keys sort last, by index
-#pragma unroll
-    for (uint32_t k = 2; k <= (uint32_t)kWave; k <<= 1) {
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t pb = (uint32_t)__shfl_xor((int)b, (int)j), pi = (uint32_t)__shfl_xor((int)i, (int)j);
-            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-            const bool mine_less = b < pb || (b == pb && i < pi);
-            if (keep_min != mine_less) {
-                b = pb;
-                i = pi;
-            }
-        }
-    }
+    SOTS_PHASE_BEGIN();
+    uint32_t b = g < p_len ? order_bits(fitness[g]) : kSelPadBits, i = g; // padding keys sort last, by index
+#ifdef SOTS_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stamp below then includes the fitness load
+#endif
+    SOTS_PHASE(8);
+    bitonic_merge<2, 1>(b, i, lane);
+    bitonic_merge<4, 2>(b, i, lane);
+    bitonic_merge<8, 4>(b, i, lane);
+    bitonic_merge<16, 8>(b, i, lane);
+    bitonic_merge<32, 16>(b, i, lane);
+    bitonic_merge<64, 32>(b, i, lane);
     runs[tid] = b;
     __syncthreads();
-    // place in the tile = lane + lower bounds in the other runs; a run of an earlier wavefront holds lower
-    // indices, so its equal keys come first (<=), a later run's do not (<)
+    SOTS_PHASE(9);
+    // place in the tile = lane + lower bounds in the other 15 runs, all 15 searches advanced level by level so
+    // that the LDS reads of a level are in flight together.  A run of an earlier wavefront holds lower indices,
+    // so its equal keys come first (count <=, i.e. < b + 1), a later run's do not (<).
+    uint32_t pos[kRuns], thr[kRuns]; // absolute positions in runs[]; "entries below thr" is what is counted
+#pragma unroll
+    for (uint32_t w = 0; w < kRuns; ++w) {
+        pos[w] = w * kWave;
+        thr[w] = w == wave ? 0u : b + (w < wave ? 1u : 0u); // own run: nothing counts (the lane is added below)
+    }
+#pragma unroll
+    for (uint32_t step = kWave / 2; step >= 1; step >>= 1) {
+#pragma unroll
+        for (uint32_t w = 0; w < kRuns; ++w) pos[w] += runs[pos[w] + step - 1] < thr[w] ? step : 0u;
+    }
     uint32_t rank = lane;
 #pragma unroll
-    for (uint32_t w = 0; w < kSelTile / kWave; ++w) {
-        if (w < wave) rank += run_lower_bound<true>(runs + w * kWave, b);
-        else if (w > wave) rank += run_lower_bound<false>(runs + w * kWave, b);
-    }
+    for (uint32_t w = 0; w < kRuns; ++w) rank += pos[w] - w * kWave + (runs[pos[w]] < thr[w] ? 1u : 0u);
+    SOTS_PHASE(10);
     const size_t o = (size_t)blockIdx.x * kSelTile + rank;
     kbits[o] = b;
     kidx[o] = i;
-    if ((rank & (kSelQuantum - 1)) == kSelQuantum - 1) samples[blockIdx.x * kSelSamples + rank / kSelQuantum] = b;
+    if ((rank & (kSelQuantum - 1)) == kSelQuantum - 1) {
+        samples[blockIdx.x * kSelSamples + rank / kSelQuantum] = b;
+        samples[gridDim.x * kSelSamples + blockIdx.x * kSelSamples + rank / kSelQuantum] = i; // indices behind all the bits
+    }
+    SOTS_PHASE(11);
 }
+
+constexpr uint32_t kSelChains = 8; // tiles searched together by one lane (independent LDS reads in flight)
 
 __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t *__restrict__ kbits,
                                                                   const uint32_t *__restrict__ kidx,
@@ -1549,158 +1603,243 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
                                                                   float *__restrict__ fout, uint32_t tiles, uint32_t need,
                                                                   uint32_t p_len, uint32_t d)
 {
+    constexpr uint32_t kWaves = kSelThreads / kWave;
     __shared__ __attribute__((aligned(16))) uint32_t staged[kSelCap];
-    __shared__ __attribute__((aligned(16))) uint32_t smp[kSelMaxTiles * kSelSamples];
+    __shared__ __attribute__((aligned(16))) uint32_t smp[kSelMaxTiles * kSelSamples], smi[kSelMaxTiles * kSelSamples];
     __shared__ uint32_t off[kSelMaxTiles + 1]; // first staged position of each tile, all passes concatenated
-    __shared__ uint32_t own_bits[kSelMaxOwn], own_tile[kSelMaxOwn], own_pos[kSelMaxOwn], own_rank[kSelMaxOwn];
-    __shared__ uint32_t wave_tot[kSelThreads / kWave];
-    __shared__ uint32_t vstar_s;
+    __shared__ uint16_t chunk_tile[kSelMaxTiles * kSelSamples]; // tile of every 256 staged positions
+    // LDS place of tile t's prefix in its pass: off[t] - w0 + kSelSkew * (t - ta).  Prefix lengths are multiples
+    // of 256 words, so without the skew every prefix would start on bank 0 and the first binary-search levels
+    // (positions 511, 255, 127, 63, 31 of eight different tiles in one instruction) would all hit bank 31.
+    __shared__ uint32_t own_bits[kSelMaxOwn], own_tile[kSelMaxOwn], own_pos[kSelMaxOwn], own_rank[kSelMaxOwn], own_src[kSelMaxOwn];
+    __shared__ uint32_t wave_tot[kWaves];
+    __shared__ unsigned long long vstar_s;
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const uint32_t ns = tiles * kSelSamples;
+    SOTS_PHASE_BEGIN();
+    SOTS_PHASE_ABS(12, tid == 0);
+    SOTS_PHASE_ABS(13, tid == kSelThreads - 1);
 
-    // ---- v* = the k-th smallest sample, k = ceil(need / 256) --------------------------------------
-    for (uint32_t e = tid; e < ns; e += kSelThreads) smp[e] = samples[e];
-    if (tid == 0) vstar_s = 0u;
+    // ---- v* = the k-th smallest sample, k = ceil(need / 256), in (fitness bits, index) order: with the
+    // index in the comparison, equal fitness values (a converged population is full of them) cannot
+    // inflate the staged prefixes ------------------------------------------------------------------
+    for (uint32_t e = tid; e < ns; e += kSelThreads) {
+        smp[e] = samples[e];
+        smi[e] = samples[ns + e];
+    }
+    if (tid == 0) vstar_s = 0ull;
     __syncthreads();
+    SOTS_PHASE(0);
     const uint32_t kth = (need + kSelQuantum - 1) / kSelQuantum;
     if (kth > ns) {
-        if (tid == 0) vstar_s = 0xFFFFFFFFu; // more rows wanted than samples can vouch for: stage everything
+        if (tid == 0) vstar_s = ~0ull; // more rows wanted than samples can vouch for: stage everything
     } else {
-        // two lanes per sample, each counts the samples below it in one half of the list; the k-th
-        // smallest VALUE is the largest sample with at most k-1 samples below it
-        const uint4 *__restrict__ s4 = reinterpret_cast<const uint4 *>(smp);
-        const uint32_t half = tid & 1u, q4 = ns / 8u; // uint4 groups per half (ns is a multiple of 16)
-        for (uint32_t sidx = tid >> 1; sidx < ns; sidx += kSelThreads / 2) {
-            const uint32_t v = smp[sidx];
+        // four lanes per sample, each counts the samples below it in a quarter of the list, 16 samples per step
+        // (ns is a multiple of 64); the k-th smallest VALUE is the largest sample with at most k-1 samples below it
+        // The four lanes of a sample read four different addresses per instruction, a quarter of the list (a
+        // multiple of 256 bytes) apart: same bank.  Each quarter therefore starts one 16-byte group further in.
+        const uint32_t q4 = ns / 16u, quarter = tid & 3u;
+        const uint4 *__restrict__ b4 = reinterpret_cast<const uint4 *>(smp) + quarter * q4;
+        const uint4 *__restrict__ i4 = reinterpret_cast<const uint4 *>(smi) + quarter * q4;
+        SOTS_PHASE_ABS(14, tid == kSelThreads - 1);
+        for (uint32_t sidx = tid >> 2; sidx < ns; sidx += kSelThreads / 4) {
+            const uint32_t vb = smp[sidx], vi = smi[sidx];
             uint32_t below = 0;
-            for (uint32_t e = half * q4; e < (half + 1u) * q4; ++e) {
-                const uint4 c = s4[e];
-                below += (c.x < v) + (c.y < v) + (c.z < v) + (c.w < v);
+            auto lt = [&](uint32_t sb, uint32_t si) { return (sb < vb || (sb == vb && si < vi)) ? 1u : 0u; };
+            for (uint32_t e0 = 0; e0 < q4; e0 += 2) {
+                const uint32_t g0 = (e0 + quarter) & (q4 - 1), g1 = (e0 + 1 + quarter) & (q4 - 1);
+                const uint4 c0 = b4[g0], c1 = b4[g1], j0 = i4[g0], j1 = i4[g1];
+                below += lt(c0.x, j0.x) + lt(c0.y, j0.y) + lt(c0.z, j0.z) + lt(c0.w, j0.w) + lt(c1.x, j1.x) + lt(c1.y, j1.y) +
+                         lt(c1.z, j1.z) + lt(c1.w, j1.w);
             }
-            below += (uint32_t)__shfl_xor((int)below, 1);
-            if (half == 0 && below < kth) atomicMax(&vstar_s, v);
+            below += lane_xor<1>(below);
+            below += lane_xor<2>(below);
+            if (quarter == 0 && below < kth) atomicMax(&vstar_s, ((unsigned long long)vb << 32) | vi);
         }
+        SOTS_PHASE_ABS(15, tid == kSelThreads - 1);
     }
     __syncthreads();
-    const uint32_t vstar = vstar_s;
+    SOTS_PHASE(1);
+    const uint32_t vstar_b = (uint32_t)(vstar_s >> 32), vstar_i = (uint32_t)vstar_s;
 
-    // ---- staged prefix of every tile, exclusive scan -> off[] ------------------------------------
+    // ---- staged prefix of every tile (256, 512, 768 or 1024 keys), exclusive scan -> off[] ---------
     {
-        uint32_t len = 0;
+        uint32_t quanta = 0; // prefix length / 256
         if (tid < tiles) {
             uint32_t m = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < kSelSamples; ++j) m += smp[tid * kSelSamples + j] <= vstar ? 1u : 0u;
-            len = m >= kSelSamples ? kSelTile : (m + 1u) * kSelQuantum;
+            for (uint32_t j = 0; j < kSelSamples; ++j) {
+                const uint32_t sb = smp[tid * kSelSamples + j], si = smi[tid * kSelSamples + j];
+                m += (sb < vstar_b || (sb == vstar_b && si <= vstar_i)) ? 1u : 0u;
+            }
+            quanta = m >= kSelSamples ? kSelSamples : m + 1u;
         }
-        uint32_t incl = len;
+        // prefix sum inside the wavefront from four ballots (quanta is 0..4), across wavefronts through LDS
+        uint32_t before_lane = 0, wave_sum = 0;
 #pragma unroll
-        for (uint32_t sh = 1; sh < (uint32_t)kWave; sh <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, (int)sh);
-            if (lane >= sh) incl += up;
+        for (uint32_t q = 1; q <= kSelSamples; ++q) {
+            const uint64_t mask = __ballot(quanta >= q);
+            before_lane += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            wave_sum += (uint32_t)__popcll(mask);
         }
-        if (lane == kWave - 1) wave_tot[wave] = incl;
+        if (lane == 0) wave_tot[wave] = wave_sum;
         __syncthreads();
-        uint32_t before = 0;
+        uint32_t before = before_lane;
         for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
-        if (tid < tiles) off[tid + 1] = before + incl;
+        if (tid < tiles) {
+            off[tid + 1] = (before + quanta) * kSelQuantum;
+            for (uint32_t q = 0; q < quanta; ++q) chunk_tile[before + q] = (uint16_t)tid;
+        }
         if (tid == 0) off[0] = 0;
     }
     __syncthreads();
+    SOTS_PHASE(2);
     const uint32_t total = off[tiles];
 
-    // ---- this workgroup's keys: an equal share of the staged positions ---------------------------
+    // ---- this workgroup's keys: an equal share of the staged positions.  Their fitness bits and row
+    // indices are requested now and land while the prefixes are staged -------------------------------
     const uint32_t share = (total + gridDim.x - 1) / gridDim.x; // <= kSelMaxOwn by the launcher's grid
-    for (uint32_t slot = tid; slot < share; slot += kSelThreads) {
-        const uint32_t g = blockIdx.x * share + slot;
-        uint32_t t = 0xFFFFFFFFu, pos = 0, bits = 0;
-        if (g < total) {
-            uint32_t lo = 0, len = tiles; // last tile with off[tile] <= g
-            while (len > 1) {
-                const uint32_t h = len >> 1;
-                lo += off[lo + h] <= g ? h : 0u;
-                len -= h;
-            }
-            pos = g - off[lo];
-            bits = kbits[(size_t)lo * kSelTile + pos];
-            if (bits != 0xFFFFFFFFu) t = lo; // padding keys move nothing
+    uint32_t my_tile = 0xFFFFFFFFu, my_pos = 0, my_bits = 0xFFFFFFFFu, my_src = 0; // slot `tid`
+    {
+        const uint32_t g = blockIdx.x * share + tid;
+        if (tid < share && g < total) {
+            my_tile = chunk_tile[g / kSelQuantum];
+            my_pos = g - off[my_tile];
+            my_bits = kbits[(size_t)my_tile * kSelTile + my_pos];
+            my_src = kidx[(size_t)my_tile * kSelTile + my_pos];
         }
-        own_tile[slot] = t;
-        own_pos[slot] = pos;
-        own_bits[slot] = bits;
-        own_rank[slot] = 0;
     }
+    SOTS_PHASE(3);
 
     // ---- passes over the staged prefixes ---------------------------------------------------------
     typedef __attribute__((address_space(3))) void *lds_ptr_t;
     const uint32_t sub = tid & (kSelLanesPerKey - 1);
+    constexpr uint32_t kRowRounds = kSelMaxOwn / kSelKeysPerRound, kColsPerLane = (2 * SOTS_MAX_DIMS + 1 + kSelLanesPerKey - 1) / kSelLanesPerKey;
+    float val[kRowRounds][kColsPerLane];
     const uint32_t passes = off[tiles - 1] / kSelWindow + 1;
     uint32_t ta = 0;
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const uint32_t w0 = pass * kSelWindow;
-        uint32_t tb = 0; // first tile that starts at or beyond the end of this window: tiles [ta, tb) are staged
-        for (uint32_t len = tiles; len > 0;) {
-            const uint32_t h = len >> 1;
-            if (off[tb + h] < w0 + kSelWindow) {
-                tb += h + 1;
-                len -= h + 1;
-            } else {
-                len = h;
+        // first tile that starts at or beyond the end of this window: tiles [ta, tb) are staged
+        uint32_t tb = tiles;
+        if (w0 + kSelWindow < total) {
+            const uint32_t t = chunk_tile[(w0 + kSelWindow) / kSelQuantum]; // the tile that owns that position
+            tb = off[t] == w0 + kSelWindow ? t : t + 1;
+        }
+        if (pass) __syncthreads(); // the previous pass's searches are done with the staging buffer
+        // wavefront w copies tiles ta + w, ta + w + 16, ...: lane m fetches the bounds of the m-th of them, then
+        // the copies are issued back to back with wavefront-uniform (readlane) arguments
+        {
+            const uint32_t mine = ta + wave + lane * kWaves;
+            const uint32_t b0 = mine < tb ? off[mine] : 0u, b1 = mine < tb ? off[mine + 1] : 0u;
+            uint32_t m = 0;
+            for (uint32_t tt = ta + wave; tt < tb; tt += kWaves, ++m) {
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)m), o1 = (uint32_t)__builtin_amdgcn_readlane((int)b1, (int)m);
+                const uint32_t *__restrict__ src = kbits + (size_t)tt * kSelTile;
+                for (uint32_t e = 0; e < o1 - o0; e += 4 * kWave) // a multiple of 256: whole wavefront instructions
+                    __builtin_amdgcn_global_load_lds(src + e + 4 * lane, (lds_ptr_t)(staged + (o0 - w0) + kSelSkew * (tt - ta) + e), 16, 0, 0);
             }
         }
-        __syncthreads(); // the previous pass's searches are done (and own_* / off[] are in place)
-        for (uint32_t tt = ta + wave; tt < tb; tt += kSelThreads / kWave) {
-            const uint32_t o = off[tt] - w0, n = off[tt + 1] - off[tt];
-            const uint32_t *__restrict__ src = kbits + (size_t)tt * kSelTile;
-            for (uint32_t e = 0; e < n; e += 4 * kWave) // n is a multiple of 256: whole wavefront instructions
-                __builtin_amdgcn_global_load_lds(src + e + 4 * lane, (lds_ptr_t)(staged + o + e), 16, 0, 0);
+        if (pass == 0) { // the own-key loads were issued before the copies, so they have landed too
+            const bool live = my_tile != 0xFFFFFFFFu && my_bits != kSelPadBits; // padding keys move nothing
+            if (tid < kSelMaxOwn) {
+                own_tile[tid] = live ? my_tile : 0xFFFFFFFFu;
+                own_pos[tid] = my_pos;
+                own_bits[tid] = my_bits;
+                own_src[tid] = my_src;
+                own_rank[tid] = 0;
+            }
         }
+        SOTS_PHASE(4);
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): this wavefront's copies have landed
         __syncthreads();
+        SOTS_PHASE(5);
+        if (pass == 0) {
+            // the rows of this workgroup's keys are requested now, before it is known which of them made it (about
+            // half do): the loads fly while the ranks are computed, eight lanes per key, lane `sub` holding row
+            // elements sub, sub + 8, ...
+#pragma unroll
+            for (uint32_t r = 0; r < kRowRounds; ++r) {
+                const uint32_t slot = r * kSelKeysPerRound + tid / kSelLanesPerKey;
+                if (slot >= share || own_tile[slot] == 0xFFFFFFFFu) continue;
+                const uint32_t src = own_src[slot];
+#pragma unroll
+                for (uint32_t q = 0; q < kColsPerLane; ++q) {
+                    const uint32_t c = sub + q * kSelLanesPerKey;
+                    if (c < d) val[r][q] = vin[(size_t)src * d + c];
+                    else if (c < 2 * d) val[r][q] = sin[(size_t)src * d + (c - d)];
+                    else if (c < 2 * d + 1) val[r][q] = fin[src];
+                }
+            }
+        }
         for (uint32_t r0 = 0; r0 < share; r0 += kSelKeysPerRound) {
             const uint32_t slot = r0 + tid / kSelLanesPerKey;
             const uint32_t t_own = slot < share ? own_tile[slot] : 0xFFFFFFFFu;
+            const bool live = t_own != 0xFFFFFFFFu;
+            const uint32_t xb = live ? own_bits[slot] : 0u, pos_own = live ? own_pos[slot] : 0u;
             uint32_t count = 0;
-            if (t_own != 0xFFFFFFFFu) {
-                const uint32_t xb = own_bits[slot], pos_own = own_pos[slot];
-                for (uint32_t tt = ta + sub; tt < tb; tt += kSelLanesPerKey) {
-                    const uint32_t base = off[tt] - w0;
-                    uint32_t len = off[tt + 1] - off[tt];
-                    const uint32_t thr = xb + (tt < t_own ? 1u : 0u); // xb <= 0xFFFFFFFE: no overflow
-                    uint32_t lo = 0;
-                    while (len > 1) {
-                        const uint32_t h = len >> 1;
-                        lo += staged[base + lo + h - 1] < thr ? h : 0u;
-                        len -= h;
-                    }
-                    lo += staged[base + lo] < thr ? 1u : 0u;
-                    count += tt == t_own ? pos_own : lo;
+            // kSelChains tiles per lane at a time, their binary searches advanced level by level.  A search keeps
+            // the ABSOLUTE position in staged[] (one add less per step); prefixes are 256, 512, 768 or 1024 long:
+            // the two top levels apply to the longer ones only, and a search that has reached the end of a
+            // 768-prefix stops (threshold 0: nothing compares below it).
+            for (uint32_t t0 = ta + sub; t0 < tb; t0 += kSelLanesPerKey * kSelChains) {
+                uint32_t base[kSelChains], n[kSelChains], thr[kSelChains], p[kSelChains];
+#pragma unroll
+                for (uint32_t m = 0; m < kSelChains; ++m) {
+                    const uint32_t tt = t0 + m * kSelLanesPerKey;
+                    const bool in = tt < tb && live;
+                    const uint32_t o0 = in ? off[tt] : w0, o1 = in ? off[tt + 1] : w0;
+                    base[m] = o0 - w0 + (in ? kSelSkew * (tt - ta) : 0u);
+                    n[m] = o1 - o0;
+                    thr[m] = in ? xb + (tt < t_own ? 1u : 0u) : 0u; // xb <= 0xFFFFFFFD for a live key: no wrap; never 0
+                    p[m] = base[m];
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < kSelChains; ++m) p[m] += (n[m] > 512u && staged[p[m] + 511] < thr[m]) ? 512u : 0u;
+#pragma unroll
+                for (uint32_t m = 0; m < kSelChains; ++m) p[m] += (n[m] > 256u && staged[p[m] + 255] < thr[m]) ? 256u : 0u;
+#pragma unroll
+                for (uint32_t m = 0; m < kSelChains; ++m) thr[m] = p[m] - base[m] >= n[m] ? 0u : thr[m];
+#pragma unroll
+                for (uint32_t step = 128; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (uint32_t m = 0; m < kSelChains; ++m) p[m] += staged[p[m] + step - 1] < thr[m] ? step : 0u;
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < kSelChains; ++m) {
+                    const uint32_t tt = t0 + m * kSelLanesPerKey;
+                    const uint32_t lb = p[m] - base[m] + (staged[p[m]] < thr[m] ? 1u : 0u);
+                    count += (tt == t_own && tt < tb) ? pos_own : lb; // the own tile counts in the pass that stages it
                 }
             }
-            count = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0xB1, 0xf, 0xf, false) + count;  // quad_perm [1,0,3,2]
-            count = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x4E, 0xf, 0xf, false) + count;  // quad_perm [2,3,0,1]
-            count = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x141, 0xf, 0xf, false) + count; // row_half_mirror
-            if (sub == 0 && t_own != 0xFFFFFFFFu) own_rank[slot] += count; // one writer per slot
+            count += lane_xor<1>(count);
+            count += lane_xor<2>(count);
+            count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x141, 0xf, 0xf, false); // row_half_mirror
+            if (sub == 0 && live) own_rank[slot] += count; // one writer per slot
         }
         ta = tb;
     }
     __syncthreads();
+    SOTS_PHASE(6);
 
-    // ---- rows of the keys that made it -----------------------------------------------------------
+    // ---- rows of the keys that made it (requested above) -------------------------------------------
     const uint32_t width = 2 * d + 1;
-    for (uint32_t r0 = 0; r0 < share; r0 += kSelKeysPerRound) {
-        const uint32_t slot = r0 + tid / kSelLanesPerKey;
-        if (slot >= share) continue;
-        const uint32_t t_own = own_tile[slot], dst = own_rank[slot];
-        if (t_own == 0xFFFFFFFFu || dst >= need) continue;
-        const uint32_t src = kidx[(size_t)t_own * kSelTile + own_pos[slot]];
-        for (uint32_t c = sub; c < width; c += kSelLanesPerKey) {
-            if (c < d) vout[(size_t)dst * d + c] = vin[(size_t)src * d + c];
-            else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = sin[(size_t)src * d + (c - d)];
-            else fout[dst] = fin[src];
+#pragma unroll
+    for (uint32_t r = 0; r < kRowRounds; ++r) {
+        const uint32_t slot = r * kSelKeysPerRound + tid / kSelLanesPerKey;
+        if (slot >= share || own_tile[slot] == 0xFFFFFFFFu) continue;
+        const uint32_t dst = own_rank[slot];
+        if (dst >= need) continue;
+#pragma unroll
+        for (uint32_t q = 0; q < kColsPerLane; ++q) {
+            const uint32_t c = sub + q * kSelLanesPerKey;
+            if (c < d) vout[(size_t)dst * d + c] = val[r][q];
+            else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = val[r][q];
+            else if (c < width) fout[dst] = val[r][q];
         }
     }
+    SOTS_PHASE(7);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2015,16 +2154,16 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
 size_t sort_keys_bytes(uint32_t p)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
-    return (size_t)n_pad * sizeof(uint64_t) + (size_t)kSelMaxTiles * kSelSamples * sizeof(uint32_t);
+    return (size_t)n_pad * sizeof(uint64_t) + (size_t)2 * kSelMaxTiles * kSelSamples * sizeof(uint32_t);
 }
 
-// The selection applies from four tiles up to kSelMaxTiles and while at most half of the rows are
+// The selection applies from kSelMinTiles tiles (P > 8192) up to kSelMaxTiles (P <= 262144) and while at most half of the rows are
 // wanted (beyond that nearly everything would be staged and the full sort is the better plan).
 bool select_applies(uint32_t p, uint32_t need)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
     const uint32_t tiles = n_pad / kSelTile;
-    return tiles >= 4 && tiles <= kSelMaxTiles && need >= 1 && (uint64_t)need * 2 <= p;
+    return tiles >= kSelMinTiles && tiles <= kSelMaxTiles && need >= 1 && (uint64_t)need * 2 <= p;
 }
 
 hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, const float *fin, float *vout,
