@@ -1593,6 +1593,7 @@ __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict_
 
 constexpr uint32_t kSelChains = 8; // tiles searched together by one lane (independent LDS reads in flight)
 
+template <uint32_t R> // samples per lane = tiles * 4 / 64
 __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t *__restrict__ kbits,
                                                                   const uint32_t *__restrict__ kidx,
                                                                   const uint32_t *__restrict__ samples,
@@ -1618,46 +1619,38 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const uint32_t ns = tiles * kSelSamples;
     SOTS_PHASE_BEGIN();
-    SOTS_PHASE_ABS(12, tid == 0);
-    SOTS_PHASE_ABS(13, tid == kSelThreads - 1);
 
     // ---- v* = the k-th smallest sample, k = ceil(need / 256), in (fitness bits, index) order: with the
     // index in the comparison, equal fitness values (a converged population is full of them) cannot
-    // inflate the staged prefixes ------------------------------------------------------------------
+    // inflate the staged prefixes.  Every lane holds R = ns / 64 samples in registers; wavefront w ranks the
+    // samples held by lanes 4w .. 4w+3: one sample at a time is broadcast as a SCALAR and compared with all
+    // ns samples by R 64-bit vector compares whose lane masks are counted by s_bcnt1 - 64 comparisons per
+    // vector instruction and no per-lane counters (a lane-per-pair count costs several times the vector work).
     for (uint32_t e = tid; e < ns; e += kSelThreads) {
         smp[e] = samples[e];
         smi[e] = samples[ns + e];
     }
-    if (tid == 0) vstar_s = 0ull;
-    __syncthreads();
-    SOTS_PHASE(0);
     const uint32_t kth = (need + kSelQuantum - 1) / kSelQuantum;
     if (kth > ns) {
-        if (tid == 0) vstar_s = ~0ull; // more rows wanted than samples can vouch for: stage everything
+        if (tid == 0) vstar_s = ~0ull; // more rows wanted than the samples can vouch for: stage everything
     } else {
-        // four lanes per sample, each counts the samples below it in a quarter of the list, 16 samples per step
-        // (ns is a multiple of 64); the k-th smallest VALUE is the largest sample with at most k-1 samples below it
-        // The four lanes of a sample read four different addresses per instruction, a quarter of the list (a
-        // multiple of 256 bytes) apart: same bank.  Each quarter therefore starts one 16-byte group further in.
-        const uint32_t q4 = ns / 16u, quarter = tid & 3u;
-        const uint4 *__restrict__ b4 = reinterpret_cast<const uint4 *>(smp) + quarter * q4;
-        const uint4 *__restrict__ i4 = reinterpret_cast<const uint4 *>(smi) + quarter * q4;
-        SOTS_PHASE_ABS(14, tid == kSelThreads - 1);
-        for (uint32_t sidx = tid >> 2; sidx < ns; sidx += kSelThreads / 4) {
-            const uint32_t vb = smp[sidx], vi = smi[sidx];
-            uint32_t below = 0;
-            auto lt = [&](uint32_t sb, uint32_t si) { return (sb < vb || (sb == vb && si < vi)) ? 1u : 0u; };
-            for (uint32_t e0 = 0; e0 < q4; e0 += 2) {
-                const uint32_t g0 = (e0 + quarter) & (q4 - 1), g1 = (e0 + 1 + quarter) & (q4 - 1);
-                const uint4 c0 = b4[g0], c1 = b4[g1], j0 = i4[g0], j1 = i4[g1];
-                below += lt(c0.x, j0.x) + lt(c0.y, j0.y) + lt(c0.z, j0.z) + lt(c0.w, j0.w) + lt(c1.x, j1.x) + lt(c1.y, j1.y) +
-                         lt(c1.z, j1.z) + lt(c1.w, j1.w);
+        unsigned long long key[R]; // (bits << 32) | index: unique, so the ranks are a permutation
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r)
+            key[r] = ((unsigned long long)samples[lane + kWave * r] << 32) | samples[ns + lane + kWave * r];
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r) {
+#pragma unroll
+            for (uint32_t l = 0; l < 4; ++l) {
+                const uint32_t src_lane = 4u * wave + l;
+                const unsigned long long v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key[r] >> 32), (int)src_lane) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[r], (int)src_lane);
+                uint32_t below = 0;
+#pragma unroll
+                for (uint32_t r2 = 0; r2 < R; ++r2) below += (uint32_t)__popcll(__ballot(key[r2] < v));
+                if (below == kth - 1 && lane == 0) vstar_s = v; // exactly one sample has this rank
             }
-            below += lane_xor<1>(below);
-            below += lane_xor<2>(below);
-            if (quarter == 0 && below < kth) atomicMax(&vstar_s, ((unsigned long long)vb << 32) | vi);
         }
-        SOTS_PHASE_ABS(15, tid == kSelThreads - 1);
     }
     __syncthreads();
     SOTS_PHASE(1);
@@ -2180,7 +2173,16 @@ hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, con
     uint32_t grid = num_cus ? num_cus : 256;
     const uint32_t min_grid = (tiles * kSelTile + kSelMaxOwn - 1) / kSelMaxOwn;
     if (grid < min_grid) grid = min_grid;
-    k_sel_rank_scatter<<<grid, kSelThreads, 0, st>>>(kbits, kidx, samples, vin, sin, fin, vout, sout, fout, tiles, need, p, d);
+#define SOTS_SEL(R) k_sel_rank_scatter<R><<<grid, kSelThreads, 0, st>>>(kbits, kidx, samples, vin, sin, fin, vout, sout, fout, tiles, need, p, d)
+    switch (tiles * kSelSamples / kWave) {
+    case 1: SOTS_SEL(1); break;
+    case 2: SOTS_SEL(2); break;
+    case 4: SOTS_SEL(4); break;
+    case 8: SOTS_SEL(8); break;
+    case 16: SOTS_SEL(16); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef SOTS_SEL
     return hipGetLastError();
 }
 

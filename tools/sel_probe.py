@@ -33,8 +33,4 @@ for j, nme in enumerate(names):
     src = rank_wgs if j < 8 else tile_wgs
     if len(src):
         print(f"  {nme:22s} {np.median(src[:, j]):9.0f} {src[:, j].max():9.0f}")
-if len(rank_wgs):
-    r = rank_wgs
-    print(f"  last wavefront starts {np.median(r[:, 13] - r[:, 12]):.0f} cycles after the first; its v* loop runs from "
-          f"{np.median(r[:, 14] - r[:, 12]):.0f} to {np.median(r[:, 15] - r[:, 12]):.0f}")
 es.close()
