@@ -198,6 +198,41 @@ int sots_inject_gathered_device(sots_ctx *ctx, const void *gathered_rows, uint32
 int sots_pack_elites_host(sots_ctx *ctx, float *rows, uint32_t n_rows);
 int sots_inject_immigrants_host(sots_ctx *ctx, const float *rows, uint32_t n_rows);
 
+/* ---- island group: one process, one island per listed device (new) ----
+ * The reference has one device per process (Evolutionary_Strategy_OpenCL.hpp:194-226).  A group owns one
+ * sots_ctx per entry of `devices` (island i: device devices[i], PRNG ids gid_base + i * P, so an island's
+ * random stream does not depend on the group size) and runs them from one host thread each.  Every
+ * `migration_interval` generations each island's best `num_elites` rows are all-gathered - RCCL
+ * (ncclCommInitAll + ncclAllGather on the islands' streams, librccl opened on first use) when the devices
+ * are distinct, device-to-device copies ordered by HIP events when islands share a device - and the other
+ * islands' rows overwrite the tail of the rows recombination reads (sots_inject_gathered_device).
+ * With one device the group is that one island and exchanges nothing. */
+#define SOTS_MAX_GROUP_DEVICES 16
+enum sots_group_flags {
+    SOTS_GROUP_OVERLAP = 1,    /* the all-gather started after generation g runs on a side stream underneath
+                                * generation g+1 and is injected after g+1's sort (rows arrive one exchange later) */
+    SOTS_GROUP_FORCE_RCCL = 2  /* use RCCL even for a single island (a one-rank communicator; exercises the
+                                * collective path on a one-GPU machine) */
+};
+typedef struct sots_group sots_group;
+int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uint32_t num_devices,
+                      uint32_t num_elites, uint32_t migration_interval, uint32_t flags, sots_group **out);
+void sots_group_destroy(sots_group *group);
+/* text of the last failure on the group (or of the last failed sots_group_create when group == NULL) */
+const char *sots_group_last_error(const sots_group *group);
+uint32_t sots_group_size(const sots_group *group);
+int sots_group_uses_rccl(const sots_group *group);
+/* island i's context: read its population, timers, info; do not destroy it or change its stream */
+sots_ctx *sots_group_island(sots_group *group, uint32_t i);
+int sots_group_set_target_audio(sots_group *group, const float *audio, uint32_t num_samples);
+int sots_group_set_target_spectrum(sots_group *group, const float *magnitudes, uint32_t num_bins);
+int sots_group_init_population(sots_group *group, uint32_t chunk_index);
+/* n generations on every island with the elite exchange; returns once everything is ENQUEUED */
+int sots_group_execute_generations(sots_group *group, uint32_t n);
+int sots_group_synchronize(sots_group *group);
+/* the island holding the lowest fitness and that fitness (blocking) */
+int sots_group_best(sots_group *group, uint32_t *island, float *fitness);
+
 /* ---- introspection ---- */
 typedef struct sots_info {
     uint32_t population_length, num_dimensions, audio_length, spectrum_row_floats;

@@ -2,6 +2,6 @@
 Evolutionary_Strategy API.  The compute path is libsots_hip.so (csrc/, gfx950 kernels
 behind the C-ABI of include/sots_hip.h); this package only binds it."""
 from . import capi, island
-from .capi import HipES, SotsError
+from .capi import HipES, HipGroup, SotsError
 
-__all__ = ["capi", "island", "HipES", "SotsError"]
+__all__ = ["capi", "island", "HipES", "HipGroup", "SotsError"]

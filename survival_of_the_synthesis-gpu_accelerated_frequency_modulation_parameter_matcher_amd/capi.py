@@ -46,7 +46,12 @@ EXPORTS = [
     "sots_stage_launch_times_ms",
     "sots_pack_elites_device", "sots_inject_immigrants_device", "sots_inject_gathered_device", "sots_pack_elites_host",
     "sots_inject_immigrants_host", "sots_get_info",
+    "sots_group_create", "sots_group_destroy", "sots_group_last_error", "sots_group_size", "sots_group_uses_rccl",
+    "sots_group_island", "sots_group_set_target_audio", "sots_group_set_target_spectrum", "sots_group_init_population",
+    "sots_group_execute_generations", "sots_group_synchronize", "sots_group_best",
 ]
+GROUP_OVERLAP, GROUP_FORCE_RCCL = 1, 2
+MAX_GROUP_DEVICES = 16
 
 
 class SotsError(RuntimeError):
@@ -121,6 +126,22 @@ def load():
     L.sots_pack_elites_host.argtypes = [vp, vp, u32]
     L.sots_inject_immigrants_host.argtypes = [vp, vp, u32]
     L.sots_get_info.argtypes = [vp, C.POINTER(Info)]
+    L.sots_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int32), u32, u32, u32, u32, C.POINTER(vp)]
+    L.sots_group_destroy.argtypes = [vp]
+    L.sots_group_destroy.restype = None
+    L.sots_group_last_error.argtypes = [vp]
+    L.sots_group_last_error.restype = C.c_char_p
+    L.sots_group_size.argtypes = [vp]
+    L.sots_group_size.restype = u32
+    L.sots_group_uses_rccl.argtypes = [vp]
+    L.sots_group_island.argtypes = [vp, u32]
+    L.sots_group_island.restype = vp
+    L.sots_group_set_target_audio.argtypes = [vp, vp, u32]
+    L.sots_group_set_target_spectrum.argtypes = [vp, vp, u32]
+    L.sots_group_init_population.argtypes = [vp, u32]
+    L.sots_group_execute_generations.argtypes = [vp, u32]
+    L.sots_group_synchronize.argtypes = [vp]
+    L.sots_group_best.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -137,13 +158,43 @@ def _nbytes(a):
     return 0 if a is None else a.nbytes
 
 
+def make_config(num_parents, num_offspring, synth_kind=SYNTH_2OP, audio_log2=10, param_min=None, param_max=None,
+                seed=0x5EED0001, workgroup_size=32, device=0, gid_base=0, num_generations=0):
+    d = SYNTH_DIMS[synth_kind]
+    cfg = Config()
+    cfg.struct_size = C.sizeof(Config)
+    cfg.num_parents, cfg.num_offspring, cfg.num_dimensions = num_parents, num_offspring, d
+    cfg.audio_length_log2, cfg.num_generations = audio_log2, num_generations
+    cfg.synth_kind, cfg.workgroup_size = synth_kind, workgroup_size
+    cfg.device, cfg.gid_base, cfg.seed = device, gid_base, seed
+    pmin = list(param_min) if param_min is not None else [0.0] * d
+    pmax = list(param_max)
+    for i in range(MAX_DIMS):
+        cfg.param_min[i] = float(pmin[i]) if i < len(pmin) else 0.0
+        cfg.param_max[i] = float(pmax[i]) if i < len(pmax) else 0.0
+    return cfg
+
+
 class HipES:
     """One evolutionary-strategy context on one MI355X (mirror of the C-ABI)."""
+
+    @classmethod
+    def borrowed(cls, handle, cfg):
+        """A view of a context owned by somebody else (an island of a HipGroup): close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.cfg = cfg
+        self.P, self.D, self.N = cfg.num_parents + cfg.num_offspring, cfg.num_dimensions, 1 << cfg.audio_length_log2
+        self.num_parents = cfg.num_parents
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        return self
 
     def __init__(self, num_parents, num_offspring, synth_kind=SYNTH_2OP, audio_log2=10,
                  param_min=None, param_max=None, seed=0x5EED0001, workgroup_size=32,
                  device=0, gid_base=0, num_generations=0):
         self.L = load()
+        self._borrowed = False
         d = SYNTH_DIMS[synth_kind]
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -172,7 +223,8 @@ class HipES:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.L.sots_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.L.sots_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -333,3 +385,62 @@ class HipES:
     def inject_immigrants(self, rows):
         r = _f32(rows)
         self._check(self.L.sots_inject_immigrants_host(self._h, _ptr(r), r.shape[0]))
+
+
+class HipGroup:
+    """Islands inside the library: one process, one island per listed device (sots_group_* of the C-ABI)."""
+
+    def __init__(self, devices, num_elites, num_parents, num_offspring, synth_kind=SYNTH_2OP, audio_log2=10,
+                 param_min=None, param_max=None, seed=0x5EED0001, workgroup_size=32, gid_base=0,
+                 migration_interval=1, overlap=False, force_rccl=False):
+        self.L = load()
+        self.cfg = make_config(num_parents, num_offspring, synth_kind, audio_log2, param_min, param_max, seed, workgroup_size,
+                               0, gid_base)
+        devs = (C.c_int32 * len(devices))(*devices)
+        flags = (GROUP_OVERLAP if overlap else 0) | (GROUP_FORCE_RCCL if force_rccl else 0)
+        h = C.c_void_p()
+        rc = self.L.sots_group_create(C.byref(self.cfg), devs, len(devices), num_elites, migration_interval, flags, C.byref(h))
+        if rc != 0:
+            raise SotsError(rc, self.L.sots_group_last_error(None).decode())
+        self._h = h
+        self.size = self.L.sots_group_size(h)
+        self.uses_rccl = bool(self.L.sots_group_uses_rccl(h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SotsError(rc, self.L.sots_group_last_error(self._h).decode())
+
+    def island(self, i):
+        h = self.L.sots_group_island(self._h, i)
+        if not h:
+            raise IndexError(i)
+        return HipES.borrowed(h, self.cfg)
+
+    def set_target_audio(self, audio):
+        a = _f32(audio)
+        self._check(self.L.sots_group_set_target_audio(self._h, _ptr(a), a.size))
+
+    def init_population(self, chunk=0):
+        self._check(self.L.sots_group_init_population(self._h, chunk))
+
+    def execute_generations(self, n):
+        self._check(self.L.sots_group_execute_generations(self._h, n))
+
+    def synchronize(self):
+        self._check(self.L.sots_group_synchronize(self._h))
+
+    def best(self):
+        i, f = C.c_uint32(), C.c_float()
+        self._check(self.L.sots_group_best(self._h, C.byref(i), C.byref(f)))
+        return i.value, f.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.sots_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,498 @@
+// sots_group.hip -- the island model inside the library: one process, one island (sots_ctx) per
+// listed device, elites exchanged by an RCCL all-gather over xGMI ("one process,
+// ncclCommInitAll over the devices, ncclAllGather of each island's best rows").  This is what the
+// C++ drop-in (Evolutionary_Strategy_HIP_Arguments::numDevices) and sots_match's
+// type.HIP.{numDevices,numElites,migrationInterval} drive; bench.py keeps one PROCESS per GPU over
+// torch.distributed, which is the same exchange seen from the other side.
+//
+//   * every island has its own host thread while generations run: a generation is 4-6 launches, and
+//     eight islands launched from one thread would be host-bound (about 4 us per launch against
+//     ~150 us of GPU work per generation);
+//   * exchange, every `interval` generations: pack (island stream) -> all-gather -> inject the other
+//     islands' rows into the tail of the breeding rows (sots_inject_gathered_device);
+//   * schedules as in island.py: same generation, or overlapped (the all-gather started after
+//     generation g runs on a side stream underneath generation g+1 and is injected after g+1's sort);
+//   * backends: RCCL (distinct devices; librccl is opened with dlopen when the first multi-device
+//     group is made, so single-GPU users never load it), or device-to-device copies ordered by HIP
+//     events when islands share a device (rehearsals and the one-GPU tests).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/sots_hip.h"
+
+namespace {
+
+thread_local std::string g_group_create_error;
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// opened once per process, on first use
+Rccl *load_rccl(std::string &err)
+{
+    static std::mutex mu;
+    static Rccl lib;
+    static bool tried = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (tried) {
+        if (!lib.handle) err = "librccl could not be loaded earlier in this process";
+        return lib.handle ? &lib : nullptr;
+    }
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib.handle) break;
+    }
+    if (!lib.handle) {
+        err = std::string("dlopen(librccl): ") + dlerror();
+        return nullptr;
+    }
+#define SOTS_SYM(field, sym)                                                   \
+    lib.field = reinterpret_cast<decltype(lib.field)>(dlsym(lib.handle, sym)); \
+    if (!lib.field) {                                                          \
+        err = std::string("librccl lacks ") + sym;                             \
+        dlclose(lib.handle);                                                   \
+        lib.handle = nullptr;                                                  \
+        return nullptr;                                                        \
+    }
+    SOTS_SYM(CommInitAll, "ncclCommInitAll")
+    SOTS_SYM(CommDestroy, "ncclCommDestroy")
+    SOTS_SYM(AllGather, "ncclAllGather")
+    SOTS_SYM(GroupStart, "ncclGroupStart")
+    SOTS_SYM(GroupEnd, "ncclGroupEnd")
+    SOTS_SYM(GetErrorString, "ncclGetErrorString")
+#undef SOTS_SYM
+    return &lib;
+}
+
+// reusable barrier for the island threads (C++17: no std::barrier)
+class HostBarrier
+{
+    std::mutex mu_;
+    std::condition_variable cv_;
+    uint32_t waiting_ = 0, phase_ = 0, n_;
+
+public:
+    explicit HostBarrier(uint32_t n) : n_(n) {}
+    void arrive_and_wait()
+    {
+        std::unique_lock<std::mutex> lock(mu_);
+        const uint32_t phase = phase_;
+        if (++waiting_ == n_) {
+            waiting_ = 0;
+            ++phase_;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lock, [&] { return phase_ != phase; });
+        }
+    }
+};
+
+struct Island {
+    sots_ctx *ctx = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr; // the island's compute stream (owned here, handed to the context)
+    hipStream_t side = nullptr;   // collective stream of the overlapped schedule
+    float *mine[2] = {nullptr, nullptr};     // packed elites, double-buffered
+    float *gathered[2] = {nullptr, nullptr}; // all islands' elites in island order
+    hipEvent_t packed[2] = {nullptr, nullptr};   // mine[b] is complete
+    hipEvent_t arrived[2] = {nullptr, nullptr};  // gathered[b] is complete
+    hipEvent_t consumed[2] = {nullptr, nullptr}; // every reader of mine[b] has issued its copy (local backend)
+    ncclComm_t comm = nullptr;
+};
+
+} // namespace
+
+struct sots_group {
+    std::vector<Island> islands;
+    sots_config island_cfg{};
+    uint32_t elites = 0, interval = 1, flags = 0, width = 0;
+    bool use_rccl = false;
+    Rccl *rccl = nullptr;
+    uint32_t generation = 0; // generations run since the last init_population
+    int pending = -1;        // buffer index of the all-gather in flight (overlapped schedule), -1 = none
+    std::mutex err_mu;       // island threads may fail at the same time
+    std::string err;
+};
+
+namespace {
+
+int gfail(sots_group *g, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g) {
+        std::lock_guard<std::mutex> lock(g->err_mu);
+        g->err = buf;
+    } else {
+        g_group_create_error = buf;
+    }
+    return code;
+}
+
+void destroy_group(sots_group *g)
+{
+    if (!g) return;
+    for (Island &is : g->islands) {
+        (void)hipSetDevice(is.device);
+        if (is.stream) (void)hipStreamSynchronize(is.stream);
+        if (is.side) (void)hipStreamSynchronize(is.side);
+        if (is.comm && g->rccl) (void)g->rccl->CommDestroy(is.comm);
+        if (is.ctx) sots_destroy(is.ctx);
+        for (int b = 0; b < 2; ++b) {
+            if (is.mine[b]) (void)hipFree(is.mine[b]);
+            if (is.gathered[b]) (void)hipFree(is.gathered[b]);
+            if (is.packed[b]) (void)hipEventDestroy(is.packed[b]);
+            if (is.arrived[b]) (void)hipEventDestroy(is.arrived[b]);
+            if (is.consumed[b]) (void)hipEventDestroy(is.consumed[b]);
+        }
+        if (is.side) (void)hipStreamDestroy(is.side);
+        if (is.stream) (void)hipStreamDestroy(is.stream);
+    }
+    delete g;
+}
+
+#define GROUP_HIP(g, call)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return gfail(g, SOTS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// Step 1 of an exchange, island i: its best rows into mine[b] on its own stream.
+int exchange_pack(sots_group *g, uint32_t i, int b)
+{
+    Island &is = g->islands[i];
+    GROUP_HIP(g, hipSetDevice(is.device));
+    // a reader of the previous use of this buffer may still be copying from it (local backend)
+    GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.consumed[b], 0));
+    if (int rc = sots_pack_elites_device(is.ctx, is.mine[b], g->elites)) return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
+    GROUP_HIP(g, hipEventRecord(is.packed[b], is.stream));
+    return SOTS_OK;
+}
+
+// Step 2 with RCCL, all islands at once from one thread (a group call, as RCCL wants for one process
+// driving several devices).  `on_side`: the collective runs on the side streams.
+int exchange_gather_rccl(sots_group *g, int b, bool on_side)
+{
+    const size_t count = (size_t)g->elites * g->width;
+    for (Island &is : g->islands)
+        if (on_side) {
+            GROUP_HIP(g, hipSetDevice(is.device));
+            GROUP_HIP(g, hipStreamWaitEvent(is.side, is.packed[b], 0));
+        }
+    ncclResult_t r = g->rccl->GroupStart();
+    if (r != ncclSuccess) return gfail(g, SOTS_ERR_HIP, "ncclGroupStart: %s", g->rccl->GetErrorString(r));
+    for (Island &is : g->islands) {
+        r = g->rccl->AllGather(is.mine[b], is.gathered[b], count, ncclFloat, is.comm, on_side ? is.side : is.stream);
+        if (r != ncclSuccess) {
+            (void)g->rccl->GroupEnd();
+            return gfail(g, SOTS_ERR_HIP, "ncclAllGather: %s", g->rccl->GetErrorString(r));
+        }
+    }
+    r = g->rccl->GroupEnd();
+    if (r != ncclSuccess) return gfail(g, SOTS_ERR_HIP, "ncclGroupEnd: %s", g->rccl->GetErrorString(r));
+    for (Island &is : g->islands) {
+        GROUP_HIP(g, hipSetDevice(is.device));
+        GROUP_HIP(g, hipEventRecord(is.arrived[b], on_side ? is.side : is.stream));
+    }
+    return SOTS_OK;
+}
+
+// Step 2 without RCCL (islands sharing a device): island i copies every island's block into its own
+// gathered[b], each copy behind the owner's `packed` event.
+int exchange_gather_copies(sots_group *g, int b, bool on_side)
+{
+    const size_t bytes = (size_t)g->elites * g->width * sizeof(float);
+    const uint32_t n = (uint32_t)g->islands.size();
+    for (uint32_t i = 0; i < n; ++i) {
+        Island &is = g->islands[i];
+        GROUP_HIP(g, hipSetDevice(is.device));
+        hipStream_t st = on_side ? is.side : is.stream;
+        for (uint32_t j = 0; j < n; ++j) {
+            Island &from = g->islands[j];
+            GROUP_HIP(g, hipStreamWaitEvent(st, from.packed[b], 0));
+            char *dst = reinterpret_cast<char *>(is.gathered[b]) + (size_t)j * bytes;
+            if (from.device == is.device) GROUP_HIP(g, hipMemcpyAsync(dst, from.mine[b], bytes, hipMemcpyDeviceToDevice, st));
+            else GROUP_HIP(g, hipMemcpyPeerAsync(dst, is.device, from.mine[b], from.device, bytes, st));
+        }
+        GROUP_HIP(g, hipEventRecord(is.arrived[b], st));
+    }
+    // mine[b] of island j may be packed again once every reader has finished: its stream then waits for all of them
+    for (uint32_t j = 0; j < n; ++j) {
+        Island &from = g->islands[j];
+        GROUP_HIP(g, hipSetDevice(from.device));
+        for (uint32_t i = 0; i < n; ++i) GROUP_HIP(g, hipStreamWaitEvent(from.stream, g->islands[i].arrived[b], 0));
+        GROUP_HIP(g, hipEventRecord(from.consumed[b], from.stream));
+    }
+    return SOTS_OK;
+}
+
+int exchange_gather(sots_group *g, int b, bool on_side)
+{
+    return g->use_rccl ? exchange_gather_rccl(g, b, on_side) : exchange_gather_copies(g, b, on_side);
+}
+
+// Step 3, island i: the other islands' rows into the tail of its breeding rows.
+int exchange_inject(sots_group *g, uint32_t i, int b)
+{
+    Island &is = g->islands[i];
+    GROUP_HIP(g, hipSetDevice(is.device));
+    GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.arrived[b], 0));
+    if (int rc = sots_inject_gathered_device(is.ctx, is.gathered[b], (uint32_t)g->islands.size(), i, g->elites))
+        return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
+    return SOTS_OK;
+}
+
+} // namespace
+
+// =======================================================================================
+extern "C" {
+
+int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uint32_t num_devices, uint32_t num_elites,
+                      uint32_t migration_interval, uint32_t flags, sots_group **out)
+{
+    if (!island_cfg || !out || (num_devices && !devices)) return gfail(nullptr, SOTS_ERR_INVALID, "sots_group_create: null argument");
+    *out = nullptr;
+    if (num_devices == 0 || num_devices > SOTS_MAX_GROUP_DEVICES)
+        return gfail(nullptr, SOTS_ERR_INVALID, "numDevices %u outside 1..%u", num_devices, SOTS_MAX_GROUP_DEVICES);
+    if (island_cfg->struct_size != sizeof(sots_config)) return gfail(nullptr, SOTS_ERR_INVALID, "sots_config.struct_size mismatch");
+    if (migration_interval == 0) migration_interval = 1;
+    const uint64_t p64 = (uint64_t)island_cfg->num_parents + island_cfg->num_offspring;
+    if (p64 * num_devices + island_cfg->gid_base > 0xFFFFFFFFull)
+        return gfail(nullptr, SOTS_ERR_INVALID, "global individual ids exceed 32 bits");
+
+    sots_group *g = new sots_group();
+    g->island_cfg = *island_cfg;
+    g->elites = num_devices > 1 ? num_elites : 0; // one island has nobody to exchange with
+    g->interval = migration_interval;
+    g->flags = flags;
+    g->width = 2 * island_cfg->num_dimensions + 1;
+    g->islands.resize(num_devices);
+
+    bool distinct = true;
+    for (uint32_t i = 0; i < num_devices; ++i)
+        for (uint32_t j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+    g->use_rccl = (num_devices > 1 && distinct) || (flags & SOTS_GROUP_FORCE_RCCL);
+    if ((flags & SOTS_GROUP_FORCE_RCCL) && !distinct) {
+        destroy_group(g);
+        return gfail(nullptr, SOTS_ERR_INVALID, "RCCL needs one distinct device per island");
+    }
+    if ((flags & SOTS_GROUP_FORCE_RCCL) && num_devices == 1) g->elites = num_elites; // exercises the collective on one rank
+
+#define CREATE_FAIL(code, ...)                      \
+    do {                                            \
+        int rc_ = gfail(nullptr, code, __VA_ARGS__); \
+        destroy_group(g);                           \
+        return rc_;                                 \
+    } while (0)
+#define CREATE_HIP(call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) CREATE_FAIL(SOTS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+    for (uint32_t i = 0; i < num_devices; ++i) {
+        Island &is = g->islands[i];
+        is.device = devices[i];
+        sots_config cfg = *island_cfg;
+        cfg.device = devices[i];
+        cfg.gid_base = island_cfg->gid_base + (uint32_t)(p64 * i); // global ids: an island's stream does not depend on the group size
+        if (int rc = sots_create(&cfg, &is.ctx)) CREATE_FAIL(rc, "island %u: %s", i, sots_last_error(nullptr));
+        CREATE_HIP(hipSetDevice(is.device));
+        CREATE_HIP(hipStreamCreateWithFlags(&is.stream, hipStreamNonBlocking));
+        CREATE_HIP(hipStreamCreateWithFlags(&is.side, hipStreamNonBlocking));
+        if (int rc = sots_set_stream(is.ctx, is.stream)) CREATE_FAIL(rc, "island %u: %s", i, sots_last_error(is.ctx));
+        const uint64_t immigrants = (uint64_t)(num_devices - 1) * g->elites;
+        if (g->elites > p64 || immigrants > island_cfg->num_parents)
+            CREATE_FAIL(SOTS_ERR_INVALID, "%u elites from each of %u other islands do not fit %u parents", g->elites, num_devices - 1,
+                        island_cfg->num_parents);
+        const size_t mine_bytes = (size_t)(g->elites ? g->elites : 1) * g->width * sizeof(float);
+        for (int b = 0; b < 2; ++b) {
+            CREATE_HIP(hipMalloc((void **)&is.mine[b], mine_bytes));
+            CREATE_HIP(hipMalloc((void **)&is.gathered[b], mine_bytes * num_devices));
+            CREATE_HIP(hipEventCreateWithFlags(&is.packed[b], hipEventDisableTiming));
+            CREATE_HIP(hipEventCreateWithFlags(&is.arrived[b], hipEventDisableTiming));
+            CREATE_HIP(hipEventCreateWithFlags(&is.consumed[b], hipEventDisableTiming));
+        }
+    }
+    if (g->use_rccl) {
+        std::string err;
+        g->rccl = load_rccl(err);
+        if (!g->rccl) CREATE_FAIL(SOTS_ERR_HIP, "RCCL unavailable: %s", err.c_str());
+        std::vector<ncclComm_t> comms(num_devices);
+        std::vector<int> devs(devices, devices + num_devices);
+        const ncclResult_t r = g->rccl->CommInitAll(comms.data(), (int)num_devices, devs.data());
+        if (r != ncclSuccess) CREATE_FAIL(SOTS_ERR_HIP, "ncclCommInitAll: %s", g->rccl->GetErrorString(r));
+        for (uint32_t i = 0; i < num_devices; ++i) g->islands[i].comm = comms[i];
+    }
+#undef CREATE_HIP
+#undef CREATE_FAIL
+    *out = g;
+    return SOTS_OK;
+}
+
+void sots_group_destroy(sots_group *g) { destroy_group(g); }
+
+const char *sots_group_last_error(const sots_group *g) { return g ? g->err.c_str() : g_group_create_error.c_str(); }
+
+uint32_t sots_group_size(const sots_group *g) { return g ? (uint32_t)g->islands.size() : 0u; }
+
+sots_ctx *sots_group_island(sots_group *g, uint32_t i) { return g && i < g->islands.size() ? g->islands[i].ctx : nullptr; }
+
+int sots_group_uses_rccl(const sots_group *g) { return g && g->use_rccl ? 1 : 0; }
+
+int sots_group_set_target_audio(sots_group *g, const float *audio, uint32_t num_samples)
+{
+    if (!g) return gfail(nullptr, SOTS_ERR_INVALID, "null group");
+    for (size_t i = 0; i < g->islands.size(); ++i)
+        if (int rc = sots_set_target_audio(g->islands[i].ctx, audio, num_samples)) return gfail(g, rc, "island %zu: %s", i, sots_last_error(g->islands[i].ctx));
+    return SOTS_OK;
+}
+
+int sots_group_set_target_spectrum(sots_group *g, const float *magnitudes, uint32_t num_bins)
+{
+    if (!g) return gfail(nullptr, SOTS_ERR_INVALID, "null group");
+    for (size_t i = 0; i < g->islands.size(); ++i)
+        if (int rc = sots_set_target_spectrum(g->islands[i].ctx, magnitudes, num_bins))
+            return gfail(g, rc, "island %zu: %s", i, sots_last_error(g->islands[i].ctx));
+    return SOTS_OK;
+}
+
+int sots_group_synchronize(sots_group *g)
+{
+    if (!g) return gfail(nullptr, SOTS_ERR_INVALID, "null group");
+    for (Island &is : g->islands) {
+        GROUP_HIP(g, hipSetDevice(is.device));
+        GROUP_HIP(g, hipStreamSynchronize(is.side));
+        GROUP_HIP(g, hipStreamSynchronize(is.stream));
+    }
+    return SOTS_OK;
+}
+
+int sots_group_init_population(sots_group *g, uint32_t chunk_index)
+{
+    if (!g) return gfail(nullptr, SOTS_ERR_INVALID, "null group");
+    if (int rc = sots_group_synchronize(g)) return rc; // an all-gather in flight is dropped with the old population
+    g->pending = -1;
+    g->generation = 0;
+    for (size_t i = 0; i < g->islands.size(); ++i)
+        if (int rc = sots_init_population(g->islands[i].ctx, chunk_index)) return gfail(g, rc, "island %zu: %s", i, sots_last_error(g->islands[i].ctx));
+    return SOTS_OK;
+}
+
+int sots_group_execute_generations(sots_group *g, uint32_t n)
+{
+    if (!g) return gfail(nullptr, SOTS_ERR_INVALID, "null group");
+    const uint32_t islands = (uint32_t)g->islands.size();
+    const bool exchange = g->elites > 0 && (islands > 1 || (g->flags & SOTS_GROUP_FORCE_RCCL));
+    const bool overlap = (g->flags & SOTS_GROUP_OVERLAP) != 0;
+    if (!exchange) { // nothing to exchange: every island just runs (still one thread each)
+        std::vector<std::thread> threads;
+        std::vector<int> rcs(islands, SOTS_OK);
+        for (uint32_t i = 1; i < islands; ++i)
+            threads.emplace_back([&, i] { rcs[i] = sots_execute_generations(g->islands[i].ctx, n); });
+        rcs[0] = sots_execute_generations(g->islands[0].ctx, n);
+        for (auto &t : threads) t.join();
+        for (uint32_t i = 0; i < islands; ++i)
+            if (rcs[i]) return gfail(g, rcs[i], "island %u: %s", i, sots_last_error(g->islands[i].ctx));
+        g->generation += n;
+        return SOTS_OK;
+    }
+
+    // One thread per island.  Between two exchanges a thread only talks to its own device; at an exchange
+    // the threads meet at a host barrier, thread 0 issues the all-gather for everybody (the collective is
+    // ordered on the device by events / by RCCL itself), they meet again and go on.  Nothing here waits
+    // for the GPU.
+    HostBarrier barrier(islands);
+    std::vector<int> rcs(islands, SOTS_OK);
+    int gather_rc = SOTS_OK;
+    int pending = g->pending;
+    const uint32_t gen0 = g->generation;
+    auto worker = [&](uint32_t i) {
+        int my_pending = pending; // every thread tracks the same value
+        int rc = SOTS_OK;
+        for (uint32_t k = 0; k < n; ++k) {
+            if (!rc) rc = sots_execute_generations(g->islands[i].ctx, 1); // a failed island keeps meeting the others at the barriers
+            const bool due = (gen0 + k + 1) % g->interval == 0;
+            if (!due) continue;
+            if (!overlap) {
+                if (!rc) rc = exchange_pack(g, i, 0);
+                barrier.arrive_and_wait(); // every island has recorded `packed`
+                if (i == 0) gather_rc = exchange_gather(g, 0, false);
+                barrier.arrive_and_wait(); // `arrived` is recorded for everybody
+                if (!rc && !gather_rc) rc = exchange_inject(g, i, 0);
+            } else {
+                // rows gathered at the previous exchange arrive now; this exchange's go out underneath the next generations
+                if (!rc && my_pending >= 0) rc = exchange_inject(g, i, my_pending);
+                const int b = my_pending == 0 ? 1 : 0;
+                if (!rc) rc = exchange_pack(g, i, b);
+                barrier.arrive_and_wait();
+                if (i == 0) gather_rc = exchange_gather(g, b, true);
+                barrier.arrive_and_wait();
+                my_pending = b;
+            }
+        }
+        rcs[i] = rc;
+        if (i == 0) pending = my_pending;
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t i = 1; i < islands; ++i) threads.emplace_back(worker, i);
+    worker(0);
+    for (auto &t : threads) t.join();
+    g->pending = overlap ? pending : -1;
+    g->generation += n;
+    if (gather_rc) return gather_rc; // g->err set by the gather
+    for (uint32_t i = 0; i < islands; ++i)
+        if (rcs[i]) return rcs[i];
+    return SOTS_OK;
+}
+
+int sots_group_best(sots_group *g, uint32_t *island, float *fitness)
+{
+    if (!g) return gfail(nullptr, SOTS_ERR_INVALID, "null group");
+    uint32_t best_i = 0;
+    float best_f = 0.0f;
+    for (uint32_t i = 0; i < g->islands.size(); ++i) {
+        Island &is = g->islands[i];
+        // row 0 of every island is its best unless immigrants landed after the last sort; their fitness
+        // travelled with them, so the minimum over the breeding rows is read
+        sots_info info;
+        if (int rc = sots_get_info(is.ctx, &info)) return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
+        std::vector<float> f(info.population_length);
+        if (int rc = sots_read_population(is.ctx, nullptr, 0, nullptr, 0, f.data(), f.size() * sizeof(float)))
+            return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
+        float m = f[0];
+        for (float x : f)
+            if (x < m) m = x;
+        if (i == 0 || m < best_f) {
+            best_f = m;
+            best_i = i;
+        }
+    }
+    if (island) *island = best_i;
+    if (fitness) *fitness = best_f;
+    return SOTS_OK;
+}
+
+} // extern "C"

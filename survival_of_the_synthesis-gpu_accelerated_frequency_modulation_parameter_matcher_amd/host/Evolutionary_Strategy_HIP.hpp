@@ -47,6 +47,17 @@ struct Evolutionary_Strategy_HIP_Arguments
     // un-instrumented loop - no events, one wall-clock "Total Audio Analysis Time" row and a
     // candidates-per-second line ("plus an un-instrumented mode").
     bool benchmarkStages = true;
+    // Island model inside this object (type.HIP.{numDevices,numElites,migrationInterval} in parameters.json;
+    // the reference picks exactly one device, ...OpenCL.hpp:194-226).  es_args.pop describes ONE island; with
+    // numDevices > 1 the object owns one island per device (devices[i], default deviceOrdinal + i), PRNG ids
+    // gidBase + i * populationLength, and every migrationInterval generations the islands' best numElites
+    // rows are all-gathered over RCCL and replace the tail of the other islands' parents.  Results are read
+    // from the island holding the best individual; stage timers are island 0's.
+    uint32_t numDevices = 1;
+    std::vector<int32_t> devices;     // empty: deviceOrdinal, deviceOrdinal + 1, ...
+    uint32_t numElites = 16;
+    uint32_t migrationInterval = 1;
+    bool overlapMigration = false;    // the all-gather runs underneath the next generation, rows arrive one exchange later
     bool verbose = true;
     std::string logDirectory = "";    // where hiplog(...).csv goes ("" = cwd)
 };
@@ -58,7 +69,8 @@ private:
     enum kernelNames_ { initPopulation = 0, recombinePopulation, mutatePopulation, synthesisePopulation, applyWindowPopulation, hipFFT, fitnessPopulation, sortPopulation, rotatePopulation };
     std::array<std::string, numKernels_> kernelNames_;
 
-    sots_ctx *ctx_ = nullptr;
+    sots_ctx *ctx_ = nullptr;       // the context results and timers are read from (island 0 / the best island of a group)
+    sots_group *group_ = nullptr;   // owns the islands when numDevices > 1
     sots_config cfg_{};
     Evolutionary_Strategy_HIP_Arguments args_;
 
@@ -68,6 +80,7 @@ private:
     std::vector<float> targetFFT_;
     std::vector<std::vector<float>> bestPerChunk_;
     std::vector<float> launchScratch_;
+    uint32_t bestIsland_ = 0;
     double candidatesPerSecond_ = 0.0;
 
     Benchmarker hipBenchmarker_;
@@ -86,6 +99,21 @@ private:
     {
         if (rc != SOTS_OK)
             throw std::runtime_error(std::string("Evolutionary_Strategy_HIP: ") + what + ": " + sots_last_error(ctx_));
+    }
+    void checkGroup(int rc, const char *what) const
+    {
+        if (rc != SOTS_OK)
+            throw std::runtime_error(std::string("Evolutionary_Strategy_HIP: ") + what + ": " + sots_group_last_error(group_));
+    }
+    // the island whose best individual is the group's best becomes the one that is read
+    void selectBestIsland()
+    {
+        if (!group_) return;
+        uint32_t island = 0;
+        float fitness = 0.0f;
+        checkGroup(sots_group_best(group_, &island, &fitness), "sots_group_best");
+        ctx_ = sots_group_island(group_, island);
+        bestIsland_ = island;
     }
     static std::string logName(const Evolutionary_Strategy_HIP_Arguments &a)
     {
@@ -115,6 +143,7 @@ private:
     void harvestTimers()
     {
         if (!args_.benchmarkStages) return;
+        if (group_) ctx_ = sots_group_island(group_, 0); // the instrumented island
         static const int stageOf[numKernels_] = {SOTS_STAGE_INIT, SOTS_STAGE_RECOMBINE, SOTS_STAGE_MUTATE, SOTS_STAGE_SYNTHESISE,
                                                  SOTS_STAGE_WINDOW, SOTS_STAGE_FFT, SOTS_STAGE_FITNESS, SOTS_STAGE_SORT, SOTS_STAGE_ROTATE};
         for (uint8_t k = 0; k < numKernels_; ++k) harvestStage(stageOf[k], kernelNames_[k]);
@@ -137,13 +166,17 @@ public:
     }
     ~Evolutionary_Strategy_HIP() override
     {
-        if (ctx_) sots_destroy(ctx_);
+        if (group_) sots_group_destroy(group_); // owns its islands
+        else if (ctx_) sots_destroy(ctx_);
         hipBenchmarker_.close();
     }
     Evolutionary_Strategy_HIP(const Evolutionary_Strategy_HIP &) = delete;
     Evolutionary_Strategy_HIP &operator=(const Evolutionary_Strategy_HIP &) = delete;
 
     sots_ctx *context() { return ctx_; }
+    sots_group *group() { return group_; }
+    uint32_t numIslands() const { return group_ ? sots_group_size(group_) : 1u; }
+    uint32_t bestIsland() const { return bestIsland_; }
     Benchmarker &benchmarker() { return hipBenchmarker_; }
     const std::vector<std::vector<float>> &bestParametersPerChunk() const { return bestPerChunk_; }
     // candidates evaluated per second of the last parameterMatchAudio (population x generations x chunks / wall time)
@@ -170,8 +203,19 @@ public:
             cfg_.param_min[i] = i < objective.paramMins.size() ? objective.paramMins[i] : 0.0f;
             cfg_.param_max[i] = i < objective.paramMaxs.size() ? objective.paramMaxs[i] : 0.0f;
         }
-        const int rc = sots_create(&cfg_, &ctx_);
-        if (rc != SOTS_OK) throw std::runtime_error(std::string("Evolutionary_Strategy_HIP: sots_create: ") + sots_last_error(nullptr));
+        if (args_.numDevices > 1) {
+            std::vector<int32_t> devs = args_.devices;
+            if (devs.empty())
+                for (uint32_t i = 0; i < args_.numDevices; ++i) devs.push_back(args_.deviceOrdinal + (int32_t)i);
+            if (devs.size() != args_.numDevices) throw std::runtime_error("Evolutionary_Strategy_HIP: devices must list numDevices entries");
+            const int rc = sots_group_create(&cfg_, devs.data(), args_.numDevices, args_.numElites, args_.migrationInterval,
+                                             args_.overlapMigration ? (uint32_t)SOTS_GROUP_OVERLAP : 0u, &group_);
+            if (rc != SOTS_OK) throw std::runtime_error(std::string("Evolutionary_Strategy_HIP: sots_group_create: ") + sots_group_last_error(nullptr));
+            ctx_ = sots_group_island(group_, 0);
+        } else {
+            const int rc = sots_create(&cfg_, &ctx_);
+            if (rc != SOTS_OK) throw std::runtime_error(std::string("Evolutionary_Strategy_HIP: sots_create: ") + sots_last_error(nullptr));
+        }
         targetFFT_.assign(objective.fftHalfSize, 0.0f);
         check(sots_timing_enable(ctx_, args_.benchmarkStages ? 1 : 0), "sots_timing_enable");
     }
@@ -185,6 +229,7 @@ public:
     }
     void readPopulationData(void *aInputPopulationValueData, void *aOutputPopulationValueData, uint32_t aPopulationValueSize, void *aInputPopulationStepData, void *aOutputPopulationStepData, uint32_t aPopulationStepSize, void *aInputPopulationFitnessData, void *aOutputPopulationFitnessData, uint32_t aPopulationFitnessSize) override
     {
+        selectBestIsland();
         check(sots_read_population(ctx_, (float *)aInputPopulationValueData, aPopulationValueSize, (float *)aInputPopulationStepData, aPopulationStepSize, (float *)aInputPopulationFitnessData, aPopulationFitnessSize), "readPopulationData");
         if (aOutputPopulationValueData || aOutputPopulationStepData || aOutputPopulationFitnessData)
             check(sots_read_population_other(ctx_, (float *)aOutputPopulationValueData, aPopulationValueSize, (float *)aOutputPopulationStepData, aPopulationStepSize, (float *)aOutputPopulationFitnessData, aPopulationFitnessSize), "readPopulationData");
@@ -212,13 +257,24 @@ public:
         check(sots_read_synth(ctx_, (float *)aOutputAudioBuffer, aOutputAudioSize, (float *)aInputFFTDataBuffer, aInputFFTSize, (float *)aInputFFTTargetBuffer, aInputFFTTargetBuffer ? objective.fftHalfSize * sizeof(float) : 0), "readSynthesizerData");
     }
 
-    void initPopulationHIP(uint32_t aChunk = 0) { check(sots_init_population(ctx_, aChunk), "initPopulation"); }
+    void initPopulationHIP(uint32_t aChunk = 0)
+    {
+        if (group_) checkGroup(sots_group_init_population(group_, aChunk), "initPopulation");
+        else check(sots_init_population(ctx_, aChunk), "initPopulation");
+    }
 
-    // the eight per-generation stages, each as its own launch sequence (...OpenCL.hpp:471-541)
-    void executeGeneration() override { check(sots_execute_generation(ctx_), "executeGeneration"); }
+    // the eight per-generation stages, each as its own launch sequence (...OpenCL.hpp:471-541); a group of
+    // islands runs the fused loop (its exchange sits between generations)
+    void executeGeneration() override
+    {
+        if (group_) checkGroup(sots_group_execute_generations(group_, 1), "executeGeneration");
+        else check(sots_execute_generation(ctx_), "executeGeneration");
+    }
     void executeAllGenerations() override
     {
-        if (args_.fusedGenerations) {
+        if (group_) {
+            checkGroup(sots_group_execute_generations(group_, numGenerations), "executeAllGenerations");
+        } else if (args_.fusedGenerations) {
             check(sots_execute_generations(ctx_, numGenerations), "executeAllGenerations");
         } else {
             for (uint32_t i = 0; i != numGenerations; ++i) executeGeneration();
@@ -230,12 +286,14 @@ public:
         // host: double window -> fp64 DFT -> magnitudes (Objective::calculateFFT), then H2D (...OpenCL.hpp:563-570)
         targetAudioLength = aTargetAudioLength;
         objective.calculateFFT(aTargetAudio, targetFFT_.data());
-        check(sots_set_target_spectrum(ctx_, targetFFT_.data(), objective.fftHalfSize), "setTargetAudio");
+        if (group_) checkGroup(sots_group_set_target_spectrum(group_, targetFFT_.data(), objective.fftHalfSize), "setTargetAudio");
+        else check(sots_set_target_spectrum(ctx_, targetFFT_.data(), objective.fftHalfSize), "setTargetAudio");
     }
     void setTargetFFT(float *aTargetFFT) override
     {
         std::copy(aTargetFFT, aTargetFFT + objective.fftHalfSize, targetFFT_.begin());
-        check(sots_set_target_spectrum(ctx_, targetFFT_.data(), objective.fftHalfSize), "setTargetFFT");
+        if (group_) checkGroup(sots_group_set_target_spectrum(group_, targetFFT_.data(), objective.fftHalfSize), "setTargetFFT");
+        else check(sots_set_target_spectrum(ctx_, targetFFT_.data(), objective.fftHalfSize), "setTargetFFT");
     }
 
     void parameterMatchAudio(float *aTargetAudio, uint32_t aTargetAudioLength) override
@@ -250,14 +308,15 @@ public:
             setTargetAudio(&aTargetAudio[chunkSize_ * i], chunkSize_);
             initPopulationHIP(i);
             executeAllGenerations();
-            check(sots_synchronize(ctx_), "synchronize");
+            if (group_) checkGroup(sots_group_synchronize(group_), "synchronize");
+            else check(sots_synchronize(ctx_), "synchronize");
             if (args_.verbose) printf("Audio chunk %u evaluated:\n", i);
             printBest();
             harvestTimers();
         }
         hipBenchmarker_.pauseTimer("Total Audio Analysis Time");
         const double totalMs = hipBenchmarker_.totalMs("Total Audio Analysis Time");
-        candidatesPerSecond_ = totalMs > 0.0 ? (double)population.populationLength * numGenerations * numChunks_ / (totalMs * 1e-3) : 0.0;
+        candidatesPerSecond_ = totalMs > 0.0 ? (double)population.populationLength * numIslands() * numGenerations * numChunks_ / (totalMs * 1e-3) : 0.0;
         if (args_.verbose) printf("Candidates evaluated per second: %.6g\n", candidatesPerSecond_);
 
         for (uint8_t k = 1; k < numKernels_; ++k)
@@ -270,6 +329,7 @@ public:
     // rotation-aware (the reference reads offset 0 whatever the rotation index, ...OpenCL.hpp:612-631)
     void printBest() override
     {
+        selectBestIsland();
         const uint32_t d = population.numDimensions;
         std::vector<float> v((size_t)population.populationLength * d), f(population.populationLength);
         check(sots_read_population(ctx_, v.data(), v.size() * sizeof(float), nullptr, 0, f.data(), f.size() * sizeof(float)), "printBest");

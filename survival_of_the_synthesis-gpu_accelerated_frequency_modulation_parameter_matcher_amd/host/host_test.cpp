@@ -123,6 +123,26 @@ int main(int argc, char **argv)
                 if (l2.rfind("sortPopulation,", 0) == 0) sscanf(l2.c_str(), "sortPopulation,%lf,%lf", &total_sort_ms, &avg_sort_ms);
         }
 
+        // island model inside the object: two islands (sharing device 0 here), elites exchanged every generation
+        double group_best = 0.0, group_rate = 0.0;
+        uint32_t group_islands = 0;
+        bool group_sorted = true;
+        {
+            auto ga = make_args(parents, offspring, 4, log2n, 30, pmax, dir);
+            ga.numDevices = 2;
+            ga.devices = {0, 0};
+            ga.numElites = 16;
+            ga.benchmarkStages = false;
+            Evolutionary_Strategy_HIP gs(ga);
+            gs.parameterMatchAudio(target.data(), n);
+            group_islands = gs.numIslands();
+            group_rate = gs.candidatesPerSecond();
+            std::vector<float> gv(P * D), gf(P);
+            gs.readPopulationData(gv.data(), nullptr, P * D * sizeof(float), nullptr, nullptr, 0, gf.data(), nullptr, P * sizeof(float));
+            group_best = gf[0];
+            for (uint32_t i = parents; i + 1 < P; ++i) group_sorted = group_sorted && !(gf[i + 1] < gf[i]);
+        }
+
         // a bad configuration must throw, not limp on
         bool threw = false;
         try {
@@ -135,10 +155,12 @@ int main(int argc, char **argv)
         printf("{\"sorted\": %s, \"aos_ok\": %s, \"best_fitness_last_chunk\": %.9g, \"host_fitness_chunk0\": %.9g, "
                "\"chunks\": %zu, \"fused_equals_staged\": %s, \"csv_header\": \"%s\", \"csv_rows\": %d, \"csv_has_total\": %s, "
                "\"bad_config_throws\": %s, \"staged_fft_pending\": %u, \"quiet_rows\": %d, \"quiet_stage_rows\": %d, "
-               "\"quiet_has_total\": %s, \"quiet_candidates_per_s\": %.6g, \"sort_total_ms\": %.9g, \"sort_avg_ms\": %.9g}\n",
+               "\"quiet_has_total\": %s, \"quiet_candidates_per_s\": %.6g, \"sort_total_ms\": %.9g, \"sort_avg_ms\": %.9g, "
+               "\"group_islands\": %u, \"group_best\": %.9g, \"group_candidates_per_s\": %.6g, \"group_tail_sorted\": %s}\n",
                sorted ? "true" : "false", aos_ok ? "true" : "false", f[0], host_fit, chunks, same ? "true" : "false",
                header.c_str(), rows, has_total ? "true" : "false", threw ? "true" : "false", staged_fft_calls, quiet_rows,
-               quiet_stage_rows, quiet_total ? "true" : "false", quiet_rate, total_sort_ms, avg_sort_ms);
+               quiet_stage_rows, quiet_total ? "true" : "false", quiet_rate, total_sort_ms, avg_sort_ms, group_islands, group_best,
+               group_rate, group_sorted ? "true" : "false");
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "host_test failed: %s\n", e.what());

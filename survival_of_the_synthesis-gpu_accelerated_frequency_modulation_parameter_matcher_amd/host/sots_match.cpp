@@ -1,7 +1,8 @@
 // sots_match.cpp -- command-line driver with the reference's interface (main.cpp:25-305):
 //     sots_match -j parameters.json
 // Reads the reference's parameters.json schema (general / audio / evolutionary / type), with
-// "type": {"implementation": "HIP", "HIP": {"workgroupSize", "device", "seed", "synth"}},
+// "type": {"implementation": "HIP", "HIP": {"workgroupSize", "device", "seed", "synth", "numDevices", "numElites",
+// "migrationInterval", "overlapMigration", "devices"}},
 // builds the target from "params" (synthesised) or "audio" (a mono WAV file), matches every
 // N-sample chunk with Evolutionary_Strategy_HIP, writes inputGenerated.wav and the
 // outputAudioPath rendering of the best match, and prints the best parameters.
@@ -247,6 +248,13 @@ int main(int argc, char *argv[])
             if (h.has("workgroupSize")) args.workgroupX = (uint32_t)h["workgroupSize"].number();
             if (h.has("device")) args.deviceOrdinal = (int32_t)h["device"].number();
             if (h.has("seed")) args.seed = (uint64_t)h["seed"].number();
+            // island model: one island of numParents + numOffspring per device, elites all-gathered over RCCL
+            if (h.has("numDevices")) args.numDevices = (uint32_t)h["numDevices"].number();
+            if (h.has("numElites")) args.numElites = (uint32_t)h["numElites"].number();
+            if (h.has("migrationInterval")) args.migrationInterval = (uint32_t)h["migrationInterval"].number();
+            if (h.has("overlapMigration")) args.overlapMigration = h["overlapMigration"].b;
+            if (h.has("devices"))
+                for (const Json &dv : h["devices"].arr) args.devices.push_back((int32_t)dv.number());
             if (h.has("synth")) {
                 const std::string s = h["synth"].str;
                 args.synthKind = s == "2op" ? SOTS_SYNTH_2OP : s == "3op_series" ? SOTS_SYNTH_3OP_SERIES
@@ -286,7 +294,7 @@ int main(int argc, char *argv[])
         es->parameterMatchAudio(targetAudio.data(), (uint32_t)targetAudio.size());
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
         std::cout << "Total time to complete: " << secs << "s" << std::endl;
-        const double evaluated = (double)es->population.populationLength * es->numGenerations * (targetAudio.size() / N);
+        const double evaluated = (double)es->population.populationLength * args.numDevices * es->numGenerations * (targetAudio.size() / N);
         std::cout << "Candidates evaluated per second: " << evaluated / secs << std::endl;
 
         const uint32_t P = es->population.populationLength;

@@ -29,6 +29,9 @@ def test_evolutionary_strategy_hip_through_base_class(tmp_path):
     # un-instrumented mode (isBenchmarking false): no hipEvents, no stage rows, only the total + a rate
     assert r["quiet_stage_rows"] == 0 and r["quiet_rows"] == 1 and r["quiet_has_total"]
     assert r["quiet_candidates_per_s"] > 0
+    # numDevices = 2 (both islands on device 0): 2 x 8192 candidates, 30 generations, elites exchanged every generation
+    assert r["group_islands"] == 2 and r["group_tail_sorted"] and r["group_candidates_per_s"] > 0
+    assert r["group_best"] < 1e-4
     # 40 generations of 8192 candidates: the CPU oracle reaches 3.3e-9 on chunk 0 and the local
     # optimum 0.0258 on chunk 1 with this seed; the best of a random population is ~0.1-0.3
     assert r["host_fitness_chunk0"] < 1e-6

@@ -90,3 +90,90 @@ def test_migrate_device_across_processes_equals_host_exchange(tmp_path, pkg, O, 
             others_v = np.concatenate([want[q][0][:elites] for q in range(world) if q != r])
             assert np.array_equal(want[r][2][breeding - n:breeding], others_f)
             assert np.array_equal(want[r][0][breeding - n:breeding], others_v)
+
+
+# ---- the island group inside the library (sots_group_*, csrc/sots_group.hip) ----------------------------------
+def test_one_device_group_is_the_plain_context(pkg, O):
+    """numDevices = 1 degrades to one island that exchanges nothing: bit-identical to a plain context; and the
+    same island with the RCCL backend forced (a one-rank communicator: librccl is opened, ncclCommInitAll and
+    ncclAllGather run on the island's stream) injects nothing and is bit-identical too."""
+    target = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, PMAX, 1024)
+    es = pkg.HipES(2048, 6144, pkg.capi.SYNTH_2OP, 10, None, PMAX, seed=0x5EED0001, workgroup_size=32)
+    es.set_target_audio(target)
+    es.init_population(0)
+    es.execute_generations(6)
+    want = es.read_population()
+    es.close()
+    for force in (False, True):
+        g = pkg.HipGroup([0], 16, 2048, 6144, pkg.capi.SYNTH_2OP, 10, None, PMAX, seed=0x5EED0001, force_rccl=force)
+        assert g.size == 1 and g.uses_rccl == force
+        g.set_target_audio(target)
+        g.init_population(0)
+        g.execute_generations(4)
+        g.execute_generations(2)
+        g.synchronize()
+        got = g.island(0).read_population()
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y), f"force_rccl={force}"
+        island, fit = g.best()
+        assert island == 0 and fit == want[2].min()
+        g.close()
+
+
+@pytest.mark.parametrize("world,overlap,interval", [(2, False, 1), (2, True, 1), (3, False, 2), (3, True, 1)])
+def test_group_of_islands_sharing_the_gpu_equals_host_exchange(pkg, O, world, overlap, interval):
+    """Several islands of one group on device 0 (event-ordered device-to-device copies stand in for RCCL, which
+    refuses two ranks on one GPU): island threads, double-buffered exchange and both schedules against the
+    single-threaded host-exchange simulation."""
+    parents, offspring, gens, elites = 2048, 6144, 6, 16
+    target = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, PMAX, 1024)
+    g = pkg.HipGroup([0] * world, elites, parents, offspring, pkg.capi.SYNTH_2OP, 10, None, PMAX, seed=0x5EED0001,
+                     migration_interval=interval, overlap=overlap)
+    assert g.size == world and not g.uses_rccl
+    g.set_target_audio(target)
+    g.init_population(0)
+    g.execute_generations(4)
+    g.execute_generations(gens - 4)      # the schedule carries over calls
+    g.synchronize()
+    got = [g.island(r).read_population() for r in range(world)]
+    # reference: the same islands, exchanging through blocking host calls every `interval` generations
+    P = parents + offspring
+    isl = []
+    for r in range(world):
+        es = pkg.HipES(parents, offspring, pkg.capi.SYNTH_2OP, 10, None, PMAX, seed=0x5EED0001, workgroup_size=32, gid_base=r * P)
+        es.set_target_audio(target)
+        es.init_population(0)
+        isl.append(es)
+    in_flight = None
+    for gen in range(1, gens + 1):
+        for es in isl:
+            es.execute_generations(1)
+        if gen % interval:
+            continue
+        if overlap and in_flight is not None:
+            for r, es in enumerate(isl):
+                es.inject_immigrants(np.concatenate([in_flight[q] for q in range(world) if q != r]))
+        packs = [es.pack_elites(elites) for es in isl]
+        if overlap:
+            in_flight = packs
+        else:
+            for r, es in enumerate(isl):
+                es.inject_immigrants(np.concatenate([packs[q] for q in range(world) if q != r]))
+    for r in range(world):
+        want = isl[r].read_population()
+        for x, y in zip(got[r], want):
+            assert np.array_equal(x, y, equal_nan=True), f"island {r}"
+    island, fit = g.best()
+    assert fit == min(float(np.nanmin(p[2])) for p in got)
+    for es in isl:
+        es.close()
+    g.close()
+
+
+def test_group_rejects_bad_arguments(pkg, O):
+    with pytest.raises(pkg.SotsError):
+        pkg.HipGroup([], 16, 64, 192, pkg.capi.SYNTH_2OP, 10, None, PMAX)
+    with pytest.raises(pkg.SotsError):
+        pkg.HipGroup([0, 0, 0, 0], 32, 64, 192, pkg.capi.SYNTH_2OP, 10, None, PMAX)   # 96 immigrants > 64 parents
+    with pytest.raises(pkg.SotsError):
+        pkg.HipGroup([0, 99], 4, 64, 192, pkg.capi.SYNTH_2OP, 10, None, PMAX)          # no such device
