@@ -25,7 +25,7 @@ for k, cs in acc.items():
     out[k]["dispatches_seen"] = max(v[1] for v in cs.values())
 json.dump(out, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(out):
-    if not (k.startswith("k_synth") or k.startswith("k_fft") or k.startswith("k_sort") or k.startswith("k_recomb")):
+    if not (k.startswith("k_synth") or k.startswith("k_fft") or k.startswith("k_sort") or k.startswith("k_sel") or k.startswith("k_recomb")):
         continue
     print(k)
     for c, v in sorted(out[k].items()):
