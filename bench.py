@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--sync-migration", action="store_true",
                     help="inject elites inside the generation that gathered them (default: the all-gather "
                          "overlaps the next generation and its rows arrive one generation later)")
+    ap.add_argument("--full-sort", action="store_true",
+                    help="sort all P rows every generation as the reference does (SOTS_SORT_FULL); default: the rows "
+                         "recombination reads are placed each generation, the rest of the order when it is read")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --share-gpu rehearses N > 1 on a 1-GPU box")
@@ -210,6 +213,8 @@ def main():
     stream = torch.cuda.Stream(device=device)
     es.set_stream(stream.cuda_stream)
     es.set_target_audio(target)
+    if args.full_sort:
+        es.set_sort_mode(pkg.capi.SORT_FULL)
     island = pkg.island.IslandExchange(rank, world, args.elites, es.D, device, overlap=not args.sync_migration)
 
     def step():
@@ -345,7 +350,10 @@ def main():
                        "islands": world, "elites_per_island": args.elites if world > 1 else 0,
                        "migration_interval": 1,
                        "migration": "none" if world == 1 else ("same generation" if args.sync_migration else "overlapped, arrives one generation later"),
-                       "parallelism": f"island x{world}"},
+                       "parallelism": f"island x{world}",
+                       "sortPopulation": "all P rows every generation (reference behaviour)" if args.full_sort else
+                                         "the rows the next recombination reads, in order, every generation; the rest of the "
+                                         "order when the population is read (DESIGN.md 4.1)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "basis": "bytes this FUSED kernel has to move (DESIGN.md 3.2), not its share of SURVEY 8(d)'s "

@@ -47,6 +47,9 @@ struct Evolutionary_Strategy_HIP_Arguments
     // un-instrumented loop - no events, one wall-clock "Total Audio Analysis Time" row and a
     // candidates-per-second line ("plus an un-instrumented mode").
     bool benchmarkStages = true;
+    // true: sortPopulation orders all P rows every generation as the reference does; false: each generation places
+    // the rows the next recombination reads and the rest of the order is produced when it is read (same results)
+    bool fullSortEveryGeneration = false;
     // Island model inside this object (type.HIP.{numDevices,numElites,migrationInterval} in parameters.json;
     // the reference picks exactly one device, ...OpenCL.hpp:194-226).  es_args.pop describes ONE island; with
     // numDevices > 1 the object owns one island per device (devices[i], default deviceOrdinal + i), PRNG ids
@@ -217,6 +220,9 @@ public:
             if (rc != SOTS_OK) throw std::runtime_error(std::string("Evolutionary_Strategy_HIP: sots_create: ") + sots_last_error(nullptr));
         }
         targetFFT_.assign(objective.fftHalfSize, 0.0f);
+        if (args_.fullSortEveryGeneration)
+            for (uint32_t i = 0; i < numIslands(); ++i)
+                check(sots_set_sort_mode(group_ ? sots_group_island(group_, i) : ctx_, SOTS_SORT_FULL), "sots_set_sort_mode");
         check(sots_timing_enable(ctx_, args_.benchmarkStages ? 1 : 0), "sots_timing_enable");
     }
     void initTargetAudio() override {}

@@ -253,6 +253,7 @@ int main(int argc, char *argv[])
             if (h.has("numElites")) args.numElites = (uint32_t)h["numElites"].number();
             if (h.has("migrationInterval")) args.migrationInterval = (uint32_t)h["migrationInterval"].number();
             if (h.has("overlapMigration")) args.overlapMigration = h["overlapMigration"].b;
+            if (h.has("fullSortEveryGeneration")) args.fullSortEveryGeneration = h["fullSortEveryGeneration"].b;
             if (h.has("devices"))
                 for (const Json &dv : h["devices"].arr) args.devices.push_back((int32_t)dv.number());
             if (h.has("synth")) {
