@@ -804,11 +804,15 @@ __device__ __forceinline__ float2 split_partner(const float2 (&z)[M / kWave], in
     return lane == 0 ? mine : make_float2(px, py);
 }
 
+// HALVE = false leaves out the two 1/2 factors: the outputs are 2 X[k], 2 X[M-k] exactly (a factor of two is
+// exact in fp32), and the fitness path folds the 1/2 into its magnitude scale - four multiplies fewer per pair.
+template <bool HALVE = true>
 __device__ __forceinline__ void split_pair(float2 a, float2 bz, float2 w, float2 &xa, float2 &xb)
 {
     const float2 b = make_float2(bz.x, -bz.y);
-    const float2 ee = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-    const float2 dd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float h = HALVE ? 0.5f : 1.0f;
+    const float2 ee = HALVE ? make_float2(h * (a.x + b.x), h * (a.y + b.y)) : make_float2(a.x + b.x, a.y + b.y);
+    const float2 dd = HALVE ? make_float2(h * (a.x - b.x), h * (a.y - b.y)) : make_float2(a.x - b.x, a.y - b.y);
     const float2 oo = make_float2(dd.y, -dd.x);
     const float2 t = cmul(oo, w);
     xa = cadd(ee, t);
@@ -816,14 +820,14 @@ __device__ __forceinline__ void split_pair(float2 a, float2 bz, float2 w, float2
     xb = make_float2(d2.x, -d2.y);
 }
 
-// |X| / N / windowFactor, Evolutionary_Strategy.hpp:517-519 / ocl_program.cl:608-611.
+// (|X| * scale - target)^2 with scale = 1 / N / windowFactor, Evolutionary_Strategy.hpp:517-519 /
+// ocl_program.cl:608-611 (one combined factor: 1/N is a power of two and the window factor is 1 to an ulp).
 // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: the transform feeding it is
-// fp32 against the oracle's fp64 anyway.
-__device__ __forceinline__ float bin_error(float2 x, float target, float inv_n, float inv_wf)
+// fp32 against the oracle's fp64 anyway.  The fused kernels pass 2 X and scale / 2: the same value bit for bit.
+__device__ __forceinline__ float bin_error(float2 x, float target, float scale)
 {
     const float raw = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
-    const float mag = raw * inv_n * inv_wf;
-    const float e = mag - target;
+    const float e = raw * scale - target;
     return e * e;
 }
 
@@ -863,6 +867,7 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     static_assert(LOG2N == 9 || LOG2N == 10, "wavefront-per-row FFT is for N <= 1024");
     __shared__ float2 lds[M + M / 8 + 1];
     const int lane = threadIdx.x;
+    const float half_scale = 0.5f * (inv_n * inv_wf); // the split below leaves a factor of two in
     const int partner_addr = ((kWave - lane) & (kWave - 1)) * 4; // ds_bpermute byte address of lane 64-l
     uint32_t ind = blockIdx.x;
     if (ind >= p_len) return;
@@ -927,10 +932,10 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
                 float2 xa, xb;
-                split_pair(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa, xb);
-                if (k == 0) xb = x_half; // the fitness skips the Nyquist bin and needs bin M/2
-                acc += bin_error(xa, tgt_s[k], inv_n, inv_wf);
-                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], inv_n, inv_wf);
+                split_pair<false>(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa, xb); // 2 X[k], 2 X[M-k]
+                if (k == 0) xb = make_float2(2.0f * x_half.x, 2.0f * x_half.y); // the fitness skips the Nyquist bin and needs bin M/2
+                acc += bin_error(xa, tgt_s[k], half_scale);
+                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], half_scale);
             }
             acc = wave_sum(acc);
             if (lane == 0) fitness[ind] = acc;
@@ -967,8 +972,8 @@ __global__ __launch_bounds__(kWave) void k_fitness(const float *__restrict__ spe
         for (int q = 0; q < E / 2; ++q) {
             const int k = lane + kWave * q;
             const int kb = k == 0 ? M / 2 : M - k;
-            acc += bin_error(row[k], target[k], inv_n, inv_wf);
-            acc += bin_error(row[kb], target[kb], inv_n, inv_wf);
+            acc += bin_error(row[k], target[k], inv_n * inv_wf);
+            acc += bin_error(row[kb], target[kb], inv_n * inv_wf);
         }
         acc = wave_sum(acc);
         if (lane == 0) fitness[ind] = acc;
@@ -1045,6 +1050,7 @@ __global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) vo
     __shared__ float tgt_s[MODE == 1 ? M + 1 : 1];
     __shared__ float red[W];
     const int tid = threadIdx.x;
+    const float half_scale = 0.5f * (inv_n * inv_wf); // the split below leaves a factor of two in
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < E; ++q) tgt_s[tid + T * q] = target[tid + T * q];
@@ -1114,14 +1120,15 @@ __global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) vo
         for (int q = 0; q < H; ++q) {
             const int k = tid + T * q;
             float2 xa, xb;
-            split_pair(lds[lds_pad(k)], lds[lds_pad((M - k) & (M - 1))], w_split[q], xa, xb);
             if constexpr (MODE == 0) {
+                split_pair(lds[lds_pad(k)], lds[lds_pad((M - k) & (M - 1))], w_split[q], xa, xb);
                 row[k] = xa;
                 row[M - k] = xb; // k = 0 lands on the Nyquist bin M
             } else {
-                if (k == 0) xb = x_half; // the fitness skips the Nyquist bin and needs bin M/2
-                acc += bin_error(xa, tgt_s[k], inv_n, inv_wf);
-                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], inv_n, inv_wf);
+                split_pair<false>(lds[lds_pad(k)], lds[lds_pad((M - k) & (M - 1))], w_split[q], xa, xb); // 2 X[k], 2 X[M-k]
+                if (k == 0) xb = make_float2(2.0f * x_half.x, 2.0f * x_half.y); // the fitness skips the Nyquist bin and needs bin M/2
+                acc += bin_error(xa, tgt_s[k], half_scale);
+                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], half_scale);
             }
         }
         if constexpr (MODE == 0) {
@@ -1163,8 +1170,8 @@ __global__ __launch_bounds__(wg_threads<LOG2N>()) void k_fitness_wg(const float 
         for (int q = 0; q < E / 2; ++q) {
             const int k = tid + T * q;
             const int kb = k == 0 ? M / 2 : M - k;
-            acc += bin_error(row[k], target[k], inv_n, inv_wf);
-            acc += bin_error(row[kb], target[kb], inv_n, inv_wf);
+            acc += bin_error(row[k], target[k], inv_n * inv_wf);
+            acc += bin_error(row[kb], target[kb], inv_n * inv_wf);
         }
         acc = wave_sum(acc);
         if ((tid & (kWave - 1)) == 0) red[tid / kWave] = acc;
