@@ -22,6 +22,8 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+#include "Objective_tables.hpp" // wavetable, window, target spectrum: one definition, shared with libsots_hip
+
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -130,13 +132,7 @@ public:
         fftWindow = new double[fftSize];
         fftWindowedAudio = new double[fftSize];
         // Hann window scaled by two, and its mean (:308-317)
-        const double two_pi = 2.0 * M_PI;
-        fftWindowFactor = 0.0f;
-        for (uint32_t i = 0; i < fftSize; i++) {
-            fftWindow[i] = (1.0 - cos((double)i * (fftOneOverSize - 1) * two_pi));
-            fftWindowFactor += fftWindow[i];
-        }
-        fftWindowFactor *= fftOneOverSize;
+        fftWindowFactor = sots_tables::window(fftWindow, fftSize);
         fftOneOverWindowFactor = 1.f / fftWindowFactor;
         initWavetable();
     }
@@ -153,9 +149,7 @@ public:
     {
         if (wavetable) return;
         wavetable = new float[wavetableSize];
-        const float one_over_table_size_minus_1 = 1.0f / ((float)wavetableSize - 1.0f);
-        for (uint32_t i = 0; i < wavetableSize; i++)
-            wavetable[i] = sinf((float)i * one_over_table_size_minus_1 * 2 * (float)M_PI);
+        sots_tables::wavetable(wavetable);
     }
     uint32_t getWavetableSize() { return wavetableSize; }
 
@@ -201,15 +195,7 @@ public:
     // window -> forward real DFT (fp64) -> |X|/N/windowFactor for k < N/2 (:524-542)
     void calculateFFT(float *input, float *output)
     {
-        for (uint32_t i = 0; i < fftSize; i++) fftWindowedAudio[i] = input[i] * fftWindow[i];
-        std::vector<std::complex<double>> bins(fftSize);
-        for (uint32_t i = 0; i < fftSize; i++) bins[i] = fftWindowedAudio[i];
-        forwardFFT(bins);
-        for (uint32_t i = 0; i < fftHalfSize; i++) {
-            const float rawMagnitude = hypotf((float)bins[i].real(), (float)bins[i].imag());
-            const float magnitudeForFFTSize = rawMagnitude * fftOneOverSize;
-            output[i] = magnitudeForFFTSize * fftOneOverWindowFactor;
-        }
+        sots_tables::target_spectrum(input, fftSize, fftWindow, fftWindowFactor, output);
     }
     void calculateJustFFT(float *input, float *output) { calculateFFT(input, output); } // :503-523
 
@@ -266,24 +252,6 @@ private:
         }
     }
     // recursive radix-2 decimation in time; n is a power of two
-    static void forwardFFT(std::vector<std::complex<double>> &a)
-    {
-        const size_t n = a.size();
-        if (n < 2) return;
-        std::vector<std::complex<double>> even(n / 2), odd(n / 2);
-        for (size_t i = 0; i < n / 2; ++i) {
-            even[i] = a[2 * i];
-            odd[i] = a[2 * i + 1];
-        }
-        forwardFFT(even);
-        forwardFFT(odd);
-        for (size_t k = 0; k < n / 2; ++k) {
-            const double ang = -2.0 * M_PI * (double)k / (double)n;
-            const std::complex<double> t = std::complex<double>(cos(ang), sin(ang)) * odd[k];
-            a[k] = even[k] + t;
-            a[k + n / 2] = even[k] - t;
-        }
-    }
 };
 
 struct Evolutionary_Strategy_Arguments

@@ -19,7 +19,7 @@ def main():
     from oracle import oracle as O
 
     pmax = [3520.0, 8.0, 3520.0, 1.0]
-    parents, offspring = 32, 96
+    parents, offspring = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (32, 96)
     P = parents + offspring
     es = O.OracleES(parents, offspring, O.SYNTH_2OP, 10, None, pmax, seed=0x5EED0001, recomb_block=32, gid_base=rank * P)
     es.set_target_audio(O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, pmax, 1024))

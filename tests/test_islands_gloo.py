@@ -18,12 +18,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def simulate(O, world, gens, elites, overlap):
+def simulate(O, world, gens, elites, overlap, parents=32, offspring=96):
     pmax = [3520.0, 8.0, 3520.0, 1.0]
     tgt = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, pmax, 1024)
     isl = []
     for r in range(world):
-        es = O.OracleES(32, 96, O.SYNTH_2OP, 10, None, pmax, seed=0x5EED0001, recomb_block=32, gid_base=r * 128)
+        es = O.OracleES(parents, offspring, O.SYNTH_2OP, 10, None, pmax, seed=0x5EED0001, recomb_block=32,
+                        gid_base=r * (parents + offspring))
         es.set_target_audio(tgt)
         es.init_population(0)
         isl.append(es)
@@ -43,8 +44,10 @@ def simulate(O, world, gens, elites, overlap):
     return [es.read_population() for es in isl]
 
 
-@pytest.mark.parametrize("world,overlap", [(2, 0), (3, 0), (2, 1), (3, 1)])
-def test_island_exchange_over_gloo(tmp_path, O, world, overlap):
+# (80, 176): numParents is not a multiple of the recombination block of 32, so the rows recombination reads are the two
+# whole parent blocks (64 rows) and the immigrants sit at THEIR tail, rows 64 - n .. 63
+@pytest.mark.parametrize("world,overlap,parents,offspring", [(2, 0, 32, 96), (3, 0, 32, 96), (2, 1, 32, 96), (3, 1, 32, 96), (2, 0, 80, 176)])
+def test_island_exchange_over_gloo(tmp_path, O, world, overlap, parents, offspring):
     gens, elites = 4, 4
     port = free_port()
     procs = []
@@ -52,12 +55,12 @@ def test_island_exchange_over_gloo(tmp_path, O, world, overlap):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_island_worker.py"),
-                                       str(tmp_path), str(gens), str(elites), str(overlap)], env=env,
+                                       str(tmp_path), str(gens), str(elites), str(overlap), str(parents), str(offspring)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out.decode()
-    want = simulate(O, world, gens, elites, overlap)
+    want = simulate(O, world, gens, elites, overlap, parents, offspring)
     got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for r in range(world):
         assert np.array_equal(got[r]["v"], want[r][0])
@@ -68,8 +71,9 @@ def test_island_exchange_over_gloo(tmp_path, O, world, overlap):
     for r in range(world):
         others = np.concatenate([got[q]["sent"][-2 if overlap else -1] for q in range(world) if q != r])
         n = others.shape[0]
-        assert np.array_equal(got[r]["f"][32 - n:32], others[:, 0])
-        assert np.array_equal(got[r]["v"][32 - n:32], others[:, 1:5])
+        breeding = max(1, parents // 32) * 32
+        assert np.array_equal(got[r]["f"][breeding - n:breeding], others[:, 0])
+        assert np.array_equal(got[r]["v"][breeding - n:breeding], others[:, 1:5])
     # islands are distinct streams (global individual ids differ)
     assert not np.array_equal(got[0]["v"], got[1]["v"])
 
