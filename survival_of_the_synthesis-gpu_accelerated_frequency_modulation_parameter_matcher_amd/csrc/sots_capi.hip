@@ -94,9 +94,11 @@ int fail(const sots_ctx *ctx, int code, const char *fmt, ...)
 #define SOTS_HIP(ctx, call)                                                                       \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
+        if (e_ != hipSuccess) {                                                                   \
+            (void)hipGetLastError(); /* reported here: do not leave it for a later launch check */ \
             return fail(ctx, SOTS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                                      \
+        }                                                                                         \
     } while (0)
 
 #define SOTS_REQUIRE_CTX(ctx) \
@@ -190,6 +192,7 @@ void free_ctx(sots_ctx *ctx)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    (void)hipGetLastError(); // nothing sticky survives a context (the launchers read hipGetLastError after each launch)
     delete ctx;
 }
 

@@ -155,6 +155,7 @@ void destroy_group(sots_group *g)
 {
     if (!g) return;
     for (Island &is : g->islands) {
+        if (!is.ctx && !is.stream) continue; // never got as far as its device
         (void)hipSetDevice(is.device);
         if (is.stream) (void)hipStreamSynchronize(is.stream);
         if (is.side) (void)hipStreamSynchronize(is.side);
@@ -170,6 +171,7 @@ void destroy_group(sots_group *g)
         if (is.side) (void)hipStreamDestroy(is.side);
         if (is.stream) (void)hipStreamDestroy(is.stream);
     }
+    (void)hipGetLastError(); // a failed creation must not leave its HIP error behind for the next launch to find
     delete g;
 }
 
