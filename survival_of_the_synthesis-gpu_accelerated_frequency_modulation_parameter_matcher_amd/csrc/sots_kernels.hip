@@ -1503,7 +1503,9 @@ constexpr uint32_t kSelSkew = 4;                    // consecutive tiles start 4
 // a tile whose prefix STARTS inside the window fits whole, skew included (at most window / 256 tiles per pass)
 constexpr uint32_t kSelWindow = 33536;
 static_assert(kSelWindow + kSelTile + kSelSkew * (kSelWindow / kSelQuantum) <= kSelCap, "staging buffer too small");
-constexpr uint32_t kSelMinTiles = 16, kSelMaxTiles = 256, kSelMaxOwn = 512;
+// 16..128 tiles: from 256 tiles on the k-th-sample search (quadratic in the tile count) and the four or more LDS
+// passes cost more than the two-level full sort (170 against 88 us at P = 262144)
+constexpr uint32_t kSelMinTiles = 16, kSelMaxTiles = 128, kSelMaxOwn = 512;
 
 // order-preserving bits of a fitness: every number (at most 0xFF800000, +inf) below NaN (0xFFFFFFFD), NaN
 // below the padding key (0xFFFFFFFE); 0xFFFFFFFF stays free so that "bits + 1" never wraps
@@ -2157,7 +2159,7 @@ size_t sort_keys_bytes(uint32_t p)
     return (size_t)n_pad * sizeof(uint64_t) + (size_t)2 * kSelMaxTiles * kSelSamples * sizeof(uint32_t);
 }
 
-// The selection applies from kSelMinTiles tiles (P > 8192) up to kSelMaxTiles (P <= 262144) and while at most half of the rows are
+// The selection applies from kSelMinTiles tiles (P > 8192) up to kSelMaxTiles (P <= 131072) and while at most half of the rows are
 // wanted (beyond that nearly everything would be staged and the full sort is the better plan).
 bool select_applies(uint32_t p, uint32_t need)
 {
@@ -2186,7 +2188,6 @@ hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, con
     case 2: SOTS_SEL(2); break;
     case 4: SOTS_SEL(4); break;
     case 8: SOTS_SEL(8); break;
-    case 16: SOTS_SEL(16); break;
     default: return hipErrorInvalidValue;
     }
 #undef SOTS_SEL
