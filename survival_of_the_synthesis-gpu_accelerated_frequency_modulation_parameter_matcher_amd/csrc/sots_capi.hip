@@ -359,7 +359,10 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     CREATE_HIP(hipMalloc((void **)&ctx->window, (size_t)ctx->N * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&ctx->twiddle, (size_t)ctx->N * sizeof(float2)));
     CREATE_HIP(hipMalloc((void **)&ctx->keys, sort_keys_bytes(ctx->P)));
-    CREATE_HIP(hipMalloc(&ctx->sort_scratch, sort_scratch_bytes(ctx->P)));
+    {
+        const size_t a = sort_scratch_bytes(ctx->P), b = select_scratch_bytes(ctx->P);
+        CREATE_HIP(hipMalloc(&ctx->sort_scratch, a > b ? a : b));
+    }
     CREATE_HIP(hipMemsetAsync(ctx->values, 0, pd_bytes, ctx->stream));
     CREATE_HIP(hipMemsetAsync(ctx->steps, 0, pd_bytes, ctx->stream));
     CREATE_HIP(hipMemsetAsync(ctx->fitness, 0, (size_t)2 * ctx->P * sizeof(float), ctx->stream));
@@ -624,7 +627,7 @@ int sots_stage_select(sots_ctx *ctx)
     {
         StageScope t(ctx, SOTS_STAGE_SORT);
         SOTS_HIP(ctx, launch_select(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
-                                    ctx->fit(dst), ctx->keys, ctx->P, ctx->D, need, ctx->num_cus));
+                                    ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D, need, ctx->num_cus));
     }
     ctx->tail_pending = true; // completed from the current (unsorted) half once sots_stage_rotate has flipped
     ctx->tail_first = 0;      // marks "selected into the other half, not rotated yet"
@@ -708,7 +711,7 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
             if (select) {
                 // the rows recombination reads, in order; the rest of the order is produced on demand
                 SOTS_HIP(ctx, launch_select(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst),
-                                            ctx->stp(dst), ctx->fit(dst), ctx->keys, ctx->P, ctx->D, need, ctx->num_cus));
+                                            ctx->stp(dst), ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D, need, ctx->num_cus));
             } else {
                 SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
                                           ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D));

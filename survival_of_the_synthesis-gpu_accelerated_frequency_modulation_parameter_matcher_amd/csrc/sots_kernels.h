@@ -97,8 +97,9 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
 // the best `need` rows in order into rows 0..need-1 of the out arrays, other rows untouched; only
 // where select_applies() (otherwise hipErrorInvalidValue)
 bool select_applies(uint32_t p, uint32_t need);
+size_t select_scratch_bytes(uint32_t p); // the sort scratch must hold at least this much
 hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, const float *fin, float *vout,
-                         float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d, uint32_t need,
+                         float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p, uint32_t d, uint32_t need,
                          uint32_t num_cus);
 
 // ---- island exchange ----

@@ -1500,12 +1500,9 @@ constexpr uint32_t kSelTile = 1024, kSelSamples = 4, kSelQuantum = kSelTile / kS
 constexpr uint32_t kSelThreads = 1024, kSelLanesPerKey = 8, kSelKeysPerRound = kSelThreads / kSelLanesPerKey;
 constexpr uint32_t kSelCap = 35328;                 // staged keys per pass: 138 KiB of LDS
 constexpr uint32_t kSelSkew = 4;                    // consecutive tiles start 4 more words (16 B) off the 1 KiB grid, see below
-// a tile whose prefix STARTS inside the window fits whole, skew included (at most window / 256 tiles per pass)
-constexpr uint32_t kSelWindow = 33536;
-static_assert(kSelWindow + kSelTile + kSelSkew * (kSelWindow / kSelQuantum) <= kSelCap, "staging buffer too small");
 // 16..128 tiles: from 256 tiles on the k-th-sample search (quadratic in the tile count) and the four or more LDS
 // passes cost more than the two-level full sort (170 against 88 us at P = 262144)
-constexpr uint32_t kSelMinTiles = 16, kSelMaxTiles = 128, kSelMaxOwn = 512;
+constexpr uint32_t kSelMinTiles = 16, kSelMaxTiles = 128, kSelMaxOwn = 512; // kSelMaxTiles: tiles the rank kernel handles (of either size)
 
 // order-preserving bits of a fitness: every number (at most 0xFF800000, +inf) below NaN (0xFFFFFFFD), NaN
 // below the padding key (0xFFFFFFFE); 0xFFFFFFFF stays free so that "bits + 1" never wraps
@@ -1600,9 +1597,66 @@ __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict_
     SOTS_PHASE(11);
 }
 
+// Four neighbouring sorted tiles of 1024 keys -> one sorted tile of 4096 with a sample every 512 keys.  For
+// populations of 128 k and more the rank kernel's work (staged keys x tiles x search depth) is quartered by
+// having a quarter of the tiles.  One workgroup per group of four: the 4096 fitness-bit words sit in LDS, a key's
+// place = its position in its own tile + its lower bounds in the three siblings (earlier tile: <=, later: <).
+constexpr uint32_t kSelBigTile = 4 * kSelTile, kSelBigQuantum = 512, kSelBigSamples = kSelBigTile / kSelBigQuantum;
+
+__global__ __launch_bounds__(kSelTile) void k_sel_merge4(const uint32_t *__restrict__ kbits, const uint32_t *__restrict__ kidx,
+                                                          uint32_t *__restrict__ obits, uint32_t *__restrict__ oidx,
+                                                          uint32_t *__restrict__ samples)
+{
+    __shared__ uint32_t s[kSelBigTile];
+    const uint32_t tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * kSelBigTile;
+    uint32_t b[4], i[4];
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t) { // thread `tid` holds position `tid` of each of the four tiles
+        b[t] = kbits[base + t * kSelTile + tid];
+        i[t] = kidx[base + t * kSelTile + tid];
+        s[t * kSelTile + tid] = b[t];
+    }
+    __syncthreads();
+    uint32_t pos[4][4], thr[4][4]; // [own tile][sibling]: absolute search positions in s[]
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t)
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            pos[t][u] = u * kSelTile;
+            thr[t][u] = u == t ? 0u : b[t] + (u < t ? 1u : 0u); // bits <= 0xFFFFFFFE: no wrap
+        }
+#pragma unroll
+    for (uint32_t step = kSelTile / 2; step >= 1; step >>= 1) {
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t)
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                if (u != t) pos[t][u] += s[pos[t][u] + step - 1] < thr[t][u] ? step : 0u;
+    }
+    const uint32_t ns = gridDim.x * kSelBigSamples;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t) {
+        uint32_t rank = tid;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u)
+            if (u != t) rank += pos[t][u] - u * kSelTile + (s[pos[t][u]] < thr[t][u] ? 1u : 0u);
+        obits[base + rank] = b[t];
+        oidx[base + rank] = i[t];
+        if ((rank & (kSelBigQuantum - 1)) == kSelBigQuantum - 1) {
+            samples[blockIdx.x * kSelBigSamples + rank / kSelBigQuantum] = b[t];
+            samples[ns + blockIdx.x * kSelBigSamples + rank / kSelBigQuantum] = i[t];
+        }
+    }
+}
+
 constexpr uint32_t kSelChains = 8; // tiles searched together by one lane (independent LDS reads in flight)
 
-template <uint32_t R> // samples per lane = tiles * 4 / 64
+// TILE keys per sorted tile, a sample every QUANT keys (1024 / 256 straight from k_sel_tiles; 4096 / 512 after
+// k_sel_merge4 for populations whose 1024-key tiles would be too many); R samples per lane = tiles * (TILE / QUANT) / 64
+// LPK lanes share a key's searches, each kSelChains tiles at a time: 8 for the 64 tiles of the 1024-key layout, 4 for
+// the <= 20 big tiles a pass stages (with 8, three quarters of the search chains would run empty)
+template <uint32_t R, uint32_t TILE, uint32_t QUANT, uint32_t LPK>
 __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t *__restrict__ kbits,
                                                                   const uint32_t *__restrict__ kidx,
                                                                   const uint32_t *__restrict__ samples,
@@ -1614,10 +1668,16 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
                                                                   uint32_t p_len, uint32_t d)
 {
     constexpr uint32_t kWaves = kSelThreads / kWave;
+    // the names of the 1024 / 256 layout, shadowed by this instantiation's values
+    constexpr uint32_t kSelTile = TILE, kSelQuantum = QUANT, kSelSamples = TILE / QUANT;
+    // a tile whose prefix STARTS inside the window fits whole, skew included (at most window / QUANT tiles per pass)
+    constexpr uint32_t kSelWindow = TILE == 1024 ? 33536 : 30720;
+    static_assert(kSelWindow + kSelTile + kSelSkew * (kSelWindow / kSelQuantum) <= kSelCap, "staging buffer too small");
+    static_assert(R * kWave <= kSelMaxTiles * sots::kSelSamples, "sample store too small");
     __shared__ __attribute__((aligned(16))) uint32_t staged[kSelCap];
-    __shared__ __attribute__((aligned(16))) uint32_t smp[kSelMaxTiles * kSelSamples], smi[kSelMaxTiles * kSelSamples];
+    __shared__ __attribute__((aligned(16))) uint32_t smp[kSelMaxTiles * sots::kSelSamples], smi[kSelMaxTiles * sots::kSelSamples];
     __shared__ uint32_t off[kSelMaxTiles + 1]; // first staged position of each tile, all passes concatenated
-    __shared__ uint16_t chunk_tile[kSelMaxTiles * kSelSamples]; // tile of every 256 staged positions
+    __shared__ uint16_t chunk_tile[kSelMaxTiles * sots::kSelSamples]; // tile of every QUANT staged positions
     // LDS place of tile t's prefix in its pass: off[t] - w0 + kSelSkew * (t - ta).  Prefix lengths are multiples
     // of 256 words, so without the skew every prefix would start on bank 0 and the first binary-search levels
     // (positions 511, 255, 127, 63, 31 of eight different tiles in one instruction) would all hit bank 31.
@@ -1775,21 +1835,19 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
                 }
             }
         }
-        for (uint32_t r0 = 0; r0 < share; r0 += kSelKeysPerRound) {
-            const uint32_t slot = r0 + tid / kSelLanesPerKey;
+        for (uint32_t r0 = 0; r0 < share; r0 += kSelThreads / LPK) {
+            const uint32_t slot = r0 + tid / LPK, ssub = tid % LPK;
             const uint32_t t_own = slot < share ? own_tile[slot] : 0xFFFFFFFFu;
             const bool live = t_own != 0xFFFFFFFFu;
             const uint32_t xb = live ? own_bits[slot] : 0u, pos_own = live ? own_pos[slot] : 0u;
             uint32_t count = 0;
             // kSelChains tiles per lane at a time, their binary searches advanced level by level.  A search keeps
-            // the ABSOLUTE position in staged[] (one add less per step); prefixes are 256, 512, 768 or 1024 long:
-            // the two top levels apply to the longer ones only, and a search that has reached the end of a
-            // 768-prefix stops (threshold 0: nothing compares below it).
-            for (uint32_t t0 = ta + sub; t0 < tb; t0 += kSelLanesPerKey * kSelChains) {
+            // the ABSOLUTE position in staged[] (one add less per step).
+            for (uint32_t t0 = ta + ssub; t0 < tb; t0 += LPK * kSelChains) {
                 uint32_t base[kSelChains], n[kSelChains], thr[kSelChains], p[kSelChains];
 #pragma unroll
                 for (uint32_t m = 0; m < kSelChains; ++m) {
-                    const uint32_t tt = t0 + m * kSelLanesPerKey;
+                    const uint32_t tt = t0 + m * LPK;
                     const bool in = tt < tb && live;
                     const uint32_t o0 = in ? off[tt] : w0, o1 = in ? off[tt + 1] : w0;
                     base[m] = o0 - w0 + (in ? kSelSkew * (tt - ta) : 0u);
@@ -1797,28 +1855,34 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
                     thr[m] = in ? xb + (tt < t_own ? 1u : 0u) : 0u; // xb <= 0xFFFFFFFD for a live key: no wrap; never 0
                     p[m] = base[m];
                 }
+                // levels of a quantum or more: only while the step stays inside the prefix (prefix lengths are
+                // multiples of the quantum, not powers of two)
 #pragma unroll
-                for (uint32_t m = 0; m < kSelChains; ++m) p[m] += (n[m] > 512u && staged[p[m] + 511] < thr[m]) ? 512u : 0u;
+                for (uint32_t step = kSelTile / 2; step >= kSelQuantum; step >>= 1) {
 #pragma unroll
-                for (uint32_t m = 0; m < kSelChains; ++m) p[m] += (n[m] > 256u && staged[p[m] + 255] < thr[m]) ? 256u : 0u;
+                    for (uint32_t m = 0; m < kSelChains; ++m)
+                        p[m] += (p[m] + step <= base[m] + n[m] && staged[p[m] + step - 1] < thr[m]) ? step : 0u;
+                }
+                // a search that has reached the end of its prefix stops (threshold 0: nothing compares below it)
 #pragma unroll
                 for (uint32_t m = 0; m < kSelChains; ++m) thr[m] = p[m] - base[m] >= n[m] ? 0u : thr[m];
 #pragma unroll
-                for (uint32_t step = 128; step >= 1; step >>= 1) {
+                for (uint32_t step = kSelQuantum / 2; step >= 1; step >>= 1) {
 #pragma unroll
                     for (uint32_t m = 0; m < kSelChains; ++m) p[m] += staged[p[m] + step - 1] < thr[m] ? step : 0u;
                 }
 #pragma unroll
                 for (uint32_t m = 0; m < kSelChains; ++m) {
-                    const uint32_t tt = t0 + m * kSelLanesPerKey;
+                    const uint32_t tt = t0 + m * LPK;
                     const uint32_t lb = p[m] - base[m] + (staged[p[m]] < thr[m] ? 1u : 0u);
                     count += (tt == t_own && tt < tb) ? pos_own : lb; // the own tile counts in the pass that stages it
                 }
             }
             count += lane_xor<1>(count);
-            count += lane_xor<2>(count);
-            count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x141, 0xf, 0xf, false); // row_half_mirror
-            if (sub == 0 && live) own_rank[slot] += count; // one writer per slot
+            if constexpr (LPK >= 4) count += lane_xor<2>(count);
+            if constexpr (LPK == 8) count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x141, 0xf, 0xf, false); // row_half_mirror
+            static_assert(LPK == 2 || LPK == 4 || LPK == 8, "the partial counts are added over 2, 4 or 8 neighbouring lanes");
+            if (ssub == 0 && live) own_rank[slot] += count; // one writer per slot
         }
         ta = tb;
     }
@@ -2159,17 +2223,27 @@ size_t sort_keys_bytes(uint32_t p)
     return (size_t)n_pad * sizeof(uint64_t) + (size_t)2 * kSelMaxTiles * kSelSamples * sizeof(uint32_t);
 }
 
-// The selection applies from kSelMinTiles tiles (P > 8192) up to kSelMaxTiles (P <= 131072) and while at most half of the rows are
-// wanted (beyond that nearly everything would be staged and the full sort is the better plan).
+// The selection applies from kSelMinTiles tiles of 1024 keys (P > 8192) while at most half of the rows are wanted
+// (beyond that nearly everything would be staged and the full sort is the better plan).  Up to 64 tiles (P <= 65536)
+// the rank kernel works on the 1024-key tiles; from 128 to 256 tiles (P <= 262144) they are first merged four by four
+// (k_sel_merge4), which quarters its work; larger populations take the two-level full sort.
+constexpr uint32_t kSelDirectTiles = 64, kSelMergedTiles = 256;
 bool select_applies(uint32_t p, uint32_t need)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
     const uint32_t tiles = n_pad / kSelTile;
-    return tiles >= kSelMinTiles && tiles <= kSelMaxTiles && need >= 1 && (uint64_t)need * 2 <= p;
+    return tiles >= kSelMinTiles && tiles <= kSelMergedTiles && need >= 1 && (uint64_t)need * 2 <= p;
+}
+
+// scratch of the merged plan: the 4096-key tiles (bits, indices) and their samples
+size_t select_scratch_bytes(uint32_t p)
+{
+    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    return (size_t)n_pad * 2 * sizeof(uint32_t) + (size_t)2 * kSelMaxTiles * kSelSamples * sizeof(uint32_t);
 }
 
 hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, const float *fin, float *vout,
-                         float *sout, float *fout, uint64_t *keys, uint32_t p, uint32_t d, uint32_t need,
+                         float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p, uint32_t d, uint32_t need,
                          uint32_t num_cus)
 {
     if (!select_applies(p, need)) return hipErrorInvalidValue;
@@ -2182,13 +2256,25 @@ hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, con
     uint32_t grid = num_cus ? num_cus : 256;
     const uint32_t min_grid = (tiles * kSelTile + kSelMaxOwn - 1) / kSelMaxOwn;
     if (grid < min_grid) grid = min_grid;
-#define SOTS_SEL(R) k_sel_rank_scatter<R><<<grid, kSelThreads, 0, st>>>(kbits, kidx, samples, vin, sin, fin, vout, sout, fout, tiles, need, p, d)
-    switch (tiles * kSelSamples / kWave) {
-    case 1: SOTS_SEL(1); break;
-    case 2: SOTS_SEL(2); break;
-    case 4: SOTS_SEL(4); break;
-    case 8: SOTS_SEL(8); break;
-    default: return hipErrorInvalidValue;
+    // lanes per key x 8 search chains = the tiles one pass stages: 64 / 32 / 16 tiles of 1024 keys, <= 20 big tiles
+#define SOTS_SEL(R, T, Q, L, KB, KI, SM, NT) \
+    k_sel_rank_scatter<R, T, Q, L><<<grid, kSelThreads, 0, st>>>(KB, KI, SM, vin, sin, fin, vout, sout, fout, NT, need, p, d)
+    if (tiles <= kSelDirectTiles) {
+        switch (tiles * kSelSamples / kWave) {
+        case 1: SOTS_SEL(1, kSelTile, kSelQuantum, 2, kbits, kidx, samples, tiles); break;
+        case 2: SOTS_SEL(2, kSelTile, kSelQuantum, 4, kbits, kidx, samples, tiles); break;
+        case 4: SOTS_SEL(4, kSelTile, kSelQuantum, 8, kbits, kidx, samples, tiles); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        uint32_t *bbits = static_cast<uint32_t *>(scratch), *bidx = bbits + n_pad, *bsamples = bidx + n_pad;
+        const uint32_t big = tiles / 4;
+        k_sel_merge4<<<big, kSelTile, 0, st>>>(kbits, kidx, bbits, bidx, bsamples);
+        switch (big * kSelBigSamples / kWave) {
+        case 4: SOTS_SEL(4, kSelBigTile, kSelBigQuantum, 4, bbits, bidx, bsamples, big); break;
+        case 8: SOTS_SEL(8, kSelBigTile, kSelBigQuantum, 4, bbits, bidx, bsamples, big); break;
+        default: return hipErrorInvalidValue;
+        }
     }
 #undef SOTS_SEL
     return hipGetLastError();
