@@ -61,6 +61,7 @@ struct sots_ctx {
     // experiment switches; fixed in the shipped library, settable from the environment only in a
     // -DSOTS_EXPERIMENT build (tools/exp_*.sh)
     bool allow_cut = true;
+    int skip_stage = 0;
     int fuse_variation = -1; // -1: by population shape, 0 / 1: forced
     // host tables
     std::vector<double> window64;
@@ -329,6 +330,7 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
         if (const char *e = getenv("SOTS_AUDIO_PAD")) pad = (uint32_t)strtoul(e, nullptr, 10) & ~3u; // floats
         if (const char *e = getenv("SOTS_SYNTH_CUT")) ctx->allow_cut = atoi(e) != 0;                 // 0: never cut the chain
         if (const char *e = getenv("SOTS_FUSE_VARIATION")) ctx->fuse_variation = atoi(e) != 0 ? 1 : 0;
+        if (const char *e = getenv("SOTS_SKIP_STAGE")) ctx->skip_stage = atoi(e); // 1: no synthesis, 2: no spectral kernel (timing ablations)
 #endif
         ctx->pitch = ctx->N + pad;
     }
@@ -690,7 +692,7 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
                                                   ctx->pd, ctx->mc, ctx->generation));
         }
         ctx->rot = dst;
-        {
+        if (ctx->skip_stage != 1) {
             StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH);
             // raw synthesis (the window is applied by the FFT kernel as it loads the row); by default the
             // kernel also makes its individuals: recombination + mutation from the sorted half
@@ -699,7 +701,7 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
                                        ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus,
                                        fuse_variation ? &var : nullptr, ctx->allow_cut));
         }
-        {
+        if (ctx->skip_stage != 2) {
             StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL);
             SOTS_HIP(ctx, launch_fft_fitness(ctx->stream, ctx->audio, ctx->window, ctx->target, ctx->fit(ctx->rot), ctx->twiddle, ctx->P,
                                              ctx->log2n, ctx->pitch, ctx->inv_n, ctx->inv_wf, ctx->num_cus, &ctx->occ));

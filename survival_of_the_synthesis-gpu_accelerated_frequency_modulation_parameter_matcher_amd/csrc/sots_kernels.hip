@@ -904,7 +904,20 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
         for (int h = 0; h < Q; ++h) dst[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
     };
     // transforms the row in `cur` (individual `ind`) after requesting row ind + 2 grid into `fill`
+#ifdef SOTS_STAMP
+    unsigned long long st_wait = 0, st_fft = 0, st_tail = 0, st_rows = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime(); // 100 MHz, common to the whole chip
+    const unsigned long long st_begin_clk = __builtin_amdgcn_s_memtime();
+#define SOTS_FFT_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define SOTS_FFT_T(var)
+#endif
     auto process = [&](float4 (&cur)[Q], float4 (&fill)[Q]) {
+        SOTS_FFT_T(t0);
+#ifdef SOTS_STAMP
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q) : "memory"); // the row in `cur` has landed (the newer request may still fly)
+#endif
+        SOTS_FFT_T(t1);
         if constexpr (WIN) {
 #pragma unroll
             for (int h = 0; h < Q; ++h)
@@ -913,6 +926,7 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
         request(fill, ind + 2 * gridDim.x);
         float2 z[E]; // z[s] = Z[lane + 64 s]
         fft_forward<M>(cur, lds, tw, twr, lane, z);
+        SOTS_FFT_T(t2);
         // bin M/2 = conj Z[M/2]; Z[M/2] = Z[0 + 64 (E/2)] is lane 0's slot E/2, and only lane 0 (k = 0) uses it
         const float2 x_half = make_float2(z[E / 2].x, -z[E / 2].y);
         if constexpr (MODE == 0) {
@@ -942,6 +956,22 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
         }
         ind += gridDim.x;
         __syncthreads(); // single-wavefront workgroup: orders this row's LDS reads before the next row's writes
+#ifdef SOTS_STAMP
+        {
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            if (st_rows == 0 && lane == 0 && blockIdx.x < 512) g_stamps[3 * 8192 + blockIdx.x * 16 + 7] = t0 - st_begin_clk; // prologue
+            st_wait += t1 - t0, st_fft += t2 - t1, st_tail += t3 - t2, st_rows += 1;
+            if (lane == 0 && blockIdx.x < 512) {
+                g_stamps[3 * 8192 + blockIdx.x * 16 + 0] = st_wait;
+                g_stamps[3 * 8192 + blockIdx.x * 16 + 1] = st_fft;
+                g_stamps[3 * 8192 + blockIdx.x * 16 + 2] = st_tail;
+                g_stamps[3 * 8192 + blockIdx.x * 16 + 3] = st_rows;
+                g_stamps[3 * 8192 + blockIdx.x * 16 + 4] = st_begin;
+                g_stamps[3 * 8192 + blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memrealtime();
+                g_stamps[3 * 8192 + blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime() - st_begin_clk;
+            }
+        }
+#endif
         return ind < p_len;
     };
     float4 b0[Q], b1[Q], b2[Q];
