@@ -330,8 +330,12 @@ template <int V> using ic = std::integral_constant<int, V>;
 // the tile.  Both execute the same sequence of trips with one workgroup barrier per trip: the
 // block handed over in trip k is consumed in trip k+1, exactly when the one-wavefront pipeline
 // would read it from registers, and the two hand-over buffers alternate with the block parity.
-template <int KIND, int SPLIT>
-__global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__restrict__ values,
+// HELP (fused generation loop, 4-gene voice, one tile per workgroup): the workgroup starts with four times its
+// wavefronts (sixteen for a full tile); each thread makes one gene of the tile's individuals (recombination source, 13 Philox draws, exp, pow), so
+// the variation runs once across 1024 lanes at four wavefronts per SIMD instead of four times in a row in each of
+// 256 lanes at one; the twelve extra wavefronts then leave and the usual four synthesise.
+template <int KIND, int SPLIT, bool HELP = false>
+__global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(const float *__restrict__ values,
                                                                const float *__restrict__ wavetable,
                                                                float *__restrict__ audio, SynthParams sp,
                                                                uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
@@ -339,6 +343,7 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
     constexpr int U = kSynthUnroll;
     static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
+    static_assert(!HELP || (SPLIT == 0 && D == 4), "the helper wavefronts serve the uncut 4-gene voice");
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
     request_wavetable(tab, wavetable);
@@ -347,7 +352,26 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     // SPLIT: wavefronts [0, pairs) are BACK, [pairs, 2 pairs) FRONT of the same 64 individuals
-    const uint32_t pairs = SPLIT ? blockDim.x / (2 * kWave) : blockDim.x / kWave;
+    const uint32_t pairs = HELP ? blockDim.x / (D * kWave) : SPLIT ? blockDim.x / (2 * kWave) : blockDim.x / kWave;
+    if constexpr (HELP) {
+        // one gene per thread; values and steps go to the other half, the values also to LDS for the four
+        // wavefronts that stay (the tile area is free until the first samples are parked)
+        float *__restrict__ made = reinterpret_cast<float *>(stage_all);
+        const uint32_t t = threadIdx.x, i1 = blockIdx.x * (pairs * kWave) + t / D, g1 = t % D;
+        if (i1 < p_len) {
+            const uint32_t src = recombine_source(i1, g1, var.pd);
+            float x = var.vin[src], st = var.sin[src];
+            mutate_gene(x, st, var.pd.gid_base + i1, g1, var.generation, var.pd, var.mc);
+            var.vout[(size_t)i1 * D + g1] = x;
+            var.sout[(size_t)i1 * D + g1] = st;
+            made[t] = x;
+        }
+        __syncthreads();
+        if (wave_id >= pairs) {
+            __builtin_amdgcn_s_waitcnt(0); // this wavefront's pieces of the table have landed before it leaves
+            return;
+        }
+    }
     const bool front = SPLIT && wave_id >= pairs;
     const uint32_t wave = front ? wave_id - pairs : wave_id; // which 64 individuals of the workgroup's tile
     float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
@@ -367,7 +391,11 @@ __global__ __launch_bounds__(kSynthWaves *kWave) void k_synth(const float *__res
         const uint32_t ind = row0 + lane < p_len ? row0 + lane : p_len - 1u;
         const bool full = row0 + kWave <= p_len; // every row of the tile exists
         float p[D];
-        if (var.vin) {
+        if constexpr (HELP) {
+            const float *__restrict__ made = reinterpret_cast<const float *>(stage_all);
+#pragma unroll
+            for (int g = 0; g < D; ++g) p[g] = made[(wave * kWave + lane) * D + g];
+        } else if (var.vin) {
             // fused generation loop: this lane's individual is made here (k_recombine_mutate's
             // arithmetic, gene by gene) and written to the other half by the wavefront that owns the row
             const bool owner = !front && row0 + lane < p_len;
@@ -2029,6 +2057,11 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     waves = waves < 1 ? 1 : waves > (uint32_t)kSynthWaves ? (uint32_t)kSynthWaves : waves;
     const bool cut = allow_cut && waves <= 2 && kind != SOTS_SYNTH_TRIPLE_PAR;
     const uint32_t threads = (cut ? 2 : 1) * waves * kWave, grid = grid_for(p, waves * kWave, cus);
+    // variation folded in, 2-operator voice, full workgroups with one tile each: sixteen wavefronts make the individuals
+    if (var.vin && kind == SOTS_SYNTH_2OP && !cut && (uint64_t)grid * waves * kWave >= p) {
+        k_synth<SOTS_SYNTH_2OP, 0, true><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        return hipGetLastError();
+    }
 #define SOTS_SYNTH_CASE(K, S)                                                                            \
     case K:                                                                                              \
         if (cut) k_synth<K, S><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); \
