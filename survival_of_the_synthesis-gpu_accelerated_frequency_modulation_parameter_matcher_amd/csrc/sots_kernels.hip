@@ -330,7 +330,7 @@ template <int V> using ic = std::integral_constant<int, V>;
 // the tile.  Both execute the same sequence of trips with one workgroup barrier per trip: the
 // block handed over in trip k is consumed in trip k+1, exactly when the one-wavefront pipeline
 // would read it from registers, and the two hand-over buffers alternate with the block parity.
-// HELP (fused generation loop, 4-gene voice, one tile per workgroup): the workgroup starts with four times its
+// HELP (fused generation loop, 4-gene voice, one or two tiles per workgroup): the workgroup starts with four times its
 // wavefronts (sixteen for a full tile); each thread makes one gene of the tile's individuals (recombination source, 13 Philox draws, exp, pow), so
 // the variation runs once across 1024 lanes at four wavefronts per SIMD instead of four times in a row in each of
 // 256 lanes at one; the twelve extra wavefronts then leave and the usual four synthesise.
@@ -353,18 +353,24 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     // SPLIT: wavefronts [0, pairs) are BACK, [pairs, 2 pairs) FRONT of the same 64 individuals
     const uint32_t pairs = HELP ? blockDim.x / (D * kWave) : SPLIT ? blockDim.x / (2 * kWave) : blockDim.x / kWave;
+    // HELP: the tiles this workgroup will synthesise (1 or 2: blockIdx, blockIdx + gridDim)
+    const uint32_t help_tiles = HELP ? (blockIdx.x * (pairs * kWave) + gridDim.x * (pairs * kWave) < p_len ? 2u : 1u) : 0u;
     if constexpr (HELP) {
-        // one gene per thread; values and steps go to the other half, the values also to LDS for the four
-        // wavefronts that stay (the tile area is free until the first samples are parked)
+        // one gene per thread and tile; values and steps go to the other half, the values also to LDS for the
+        // wavefronts that stay (the tile area is free until the first samples are parked; they take the second tile's
+        // values into registers before they start on the first)
         float *__restrict__ made = reinterpret_cast<float *>(stage_all);
-        const uint32_t t = threadIdx.x, i1 = blockIdx.x * (pairs * kWave) + t / D, g1 = t % D;
-        if (i1 < p_len) {
-            const uint32_t src = recombine_source(i1, g1, var.pd);
-            float x = var.vin[src], st = var.sin[src];
-            mutate_gene(x, st, var.pd.gid_base + i1, g1, var.generation, var.pd, var.mc);
-            var.vout[(size_t)i1 * D + g1] = x;
-            var.sout[(size_t)i1 * D + g1] = st;
-            made[t] = x;
+        const uint32_t t = threadIdx.x, g1 = t % D;
+        for (uint32_t kt = 0; kt < help_tiles; ++kt) {
+            const uint32_t i1 = (blockIdx.x + kt * gridDim.x) * (pairs * kWave) + t / D;
+            if (i1 < p_len) {
+                const uint32_t src = recombine_source(i1, g1, var.pd);
+                float x = var.vin[src], st = var.sin[src];
+                mutate_gene(x, st, var.pd.gid_base + i1, g1, var.generation, var.pd, var.mc);
+                var.vout[(size_t)i1 * D + g1] = x;
+                var.sout[(size_t)i1 * D + g1] = st;
+                made[kt * (pairs * kWave * D) + t] = x;
+            }
         }
         __syncthreads();
         if (wave_id >= pairs) {
@@ -386,15 +392,24 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
     const uint32_t lane_off = r8 * pitch + 4u * l7; // floats, relative to the group's first row
 
     const uint32_t rows_per_block = pairs * kWave;
+    float help_next[HELP ? D : 1]; // HELP: the second tile's values
     for (uint32_t base = blockIdx.x * rows_per_block; base < p_len; base += gridDim.x * rows_per_block) {
         const uint32_t row0 = base + wave * kWave; // first row of this wavefront
         const uint32_t ind = row0 + lane < p_len ? row0 + lane : p_len - 1u;
         const bool full = row0 + kWave <= p_len; // every row of the tile exists
         float p[D];
         if constexpr (HELP) {
-            const float *__restrict__ made = reinterpret_cast<const float *>(stage_all);
+            if (base == blockIdx.x * rows_per_block) { // first tile: both tiles' values leave LDS now
+                const float *__restrict__ made = reinterpret_cast<const float *>(stage_all);
 #pragma unroll
-            for (int g = 0; g < D; ++g) p[g] = made[(wave * kWave + lane) * D + g];
+                for (int g = 0; g < D; ++g) {
+                    p[g] = made[(wave * kWave + lane) * D + g];
+                    help_next[g] = help_tiles > 1 ? made[rows_per_block * D + (wave * kWave + lane) * D + g] : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < D; ++g) p[g] = help_next[g];
+            }
         } else if (var.vin) {
             // fused generation loop: this lane's individual is made here (k_recombine_mutate's
             // arithmetic, gene by gene) and written to the other half by the wavefront that owns the row
@@ -2058,7 +2073,7 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     const bool cut = allow_cut && waves <= 2 && kind != SOTS_SYNTH_TRIPLE_PAR;
     const uint32_t threads = (cut ? 2 : 1) * waves * kWave, grid = grid_for(p, waves * kWave, cus);
     // variation folded in, 2-operator voice, full workgroups with one tile each: sixteen wavefronts make the individuals
-    if (var.vin && kind == SOTS_SYNTH_2OP && !cut && (uint64_t)grid * waves * kWave >= p) {
+    if (var.vin && kind == SOTS_SYNTH_2OP && !cut && (uint64_t)grid * waves * kWave * 2 >= p) { // one or two tiles per workgroup
         k_synth<SOTS_SYNTH_2OP, 0, true><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
         return hipGetLastError();
     }
