@@ -334,8 +334,10 @@ template <int V> using ic = std::integral_constant<int, V>;
 // wavefronts (sixteen for a full tile); each thread makes one gene of the tile's individuals (recombination source, 13 Philox draws, exp, pow), so
 // the variation runs once across 1024 lanes at four wavefronts per SIMD instead of four times in a row in each of
 // 256 lanes at one; the twelve extra wavefronts then leave and the usual four synthesise.
-template <int KIND, int SPLIT, bool HELP = false>
-__global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(const float *__restrict__ values,
+// SPLIT2 > SPLIT: a second cut in front of operator SPLIT2 - three wavefronts per 64 individuals (stages of operators
+// [0, SPLIT), [SPLIT, SPLIT2), [SPLIT2, OPS)), two hand-over links; for the 4-operator voice at <= 128 individuals per CU
+template <int KIND, int SPLIT, bool HELP = false, int SPLIT2 = 0>
+__global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(const float *__restrict__ values,
                                                                const float *__restrict__ wavetable,
                                                                float *__restrict__ audio, SynthParams sp,
                                                                uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
@@ -343,7 +345,11 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
     constexpr int U = kSynthUnroll;
     static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
+    static_assert(SPLIT2 == 0 || (SPLIT > 0 && SPLIT2 > SPLIT && SPLIT2 < OPS), "the second cut lies behind the first");
     static_assert(!HELP || (SPLIT == 0 && D == 4), "the helper wavefronts serve the uncut 4-gene voice");
+    constexpr int STAGES = 1 + (SPLIT > 0 ? 1 : 0) + (SPLIT2 > 0 ? 1 : 0);
+    // stage of operator S: 0 = the chain's head ... STAGES-1 = its tail (which also owns the tile)
+    auto stage_of = [](int S) constexpr { return SPLIT == 0 ? 0 : S < SPLIT ? 0 : (SPLIT2 > 0 && S >= SPLIT2) ? 2 : 1; };
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
     request_wavetable(tab, wavetable);
@@ -351,8 +357,8 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    // SPLIT: wavefronts [0, pairs) are BACK, [pairs, 2 pairs) FRONT of the same 64 individuals
-    const uint32_t pairs = HELP ? blockDim.x / (D * kWave) : SPLIT ? blockDim.x / (2 * kWave) : blockDim.x / kWave;
+    // cut kernels: wavefronts [0, pairs) are the TAIL stage, [pairs, 2 pairs) the stage before it, ... of the same 64 individuals
+    const uint32_t pairs = HELP ? blockDim.x / (D * kWave) : blockDim.x / (STAGES * kWave);
     // HELP: the tiles this workgroup will synthesise (1 or 2: blockIdx, blockIdx + gridDim)
     const uint32_t help_tiles = HELP ? (blockIdx.x * (pairs * kWave) + gridDim.x * (pairs * kWave) < p_len ? 2u : 1u) : 0u;
     if constexpr (HELP) {
@@ -378,11 +384,14 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
             return;
         }
     }
-    const bool front = SPLIT && wave_id >= pairs;
-    const uint32_t wave = front ? wave_id - pairs : wave_id; // which 64 individuals of the workgroup's tile
+    const uint32_t rho = SPLIT ? wave_id / pairs : 0u;          // 0: tail stage
+    const int my_stage = STAGES - 1 - (int)rho;
+    const bool front = my_stage != STAGES - 1;                  // not the tail: no tile, no stores
+    const uint32_t wave = wave_id - rho * pairs;                // which 64 individuals of the workgroup's tile
     float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
-    // hand-over buffers [parity][U/4][lane] of 16 bytes behind the (at most two) tiles of a cut kernel
-    float4 *__restrict__ xbuf = stage_all + 2 * kWave * kStageChunks + wave * (2 * (U / 4) * kWave);
+    // hand-over buffers [link][pair][parity][U/4][lane] of 16 bytes behind the (at most two) tiles of a cut kernel
+    float4 *__restrict__ xbuf0 = stage_all + 2 * kWave * kStageChunks + wave * (2 * (U / 4) * kWave);
+    float4 *__restrict__ xbuf1 = xbuf0 + 2 * (2 * (U / 4) * kWave);
     // write side: lane = row; chunk q of the row lives in slot q ^ (row & 7)
     float4 *__restrict__ wr = stage + lane * kStageChunks;
     const uint32_t l7 = lane & 7u;
@@ -475,8 +484,12 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
             auto op = [&](auto s_tag, auto q_tag) {
                 constexpr int S = decltype(s_tag)::value, Q = decltype(q_tag)::value;
                 if constexpr (SPLIT > 0) {
-                    if (front != (S < SPLIT)) return; // the other wavefront's operator
+                    if (stage_of(S) != my_stage) return; // another wavefront's operator
                 }
+                constexpr bool CONSUMES = SPLIT > 0 && S > 0 && stage_of(S) != stage_of(S - 1);
+                constexpr bool PRODUCES = SPLIT > 0 && S + 1 < OPS && stage_of(S + 1) != stage_of(S);
+                float4 *__restrict__ xin = (S > 0 && stage_of(S > 0 ? S - 1 : 0) == 1) ? xbuf1 : xbuf0;  // link = the producer's stage
+                float4 *__restrict__ xout = stage_of(S) == 1 ? xbuf1 : xbuf0;
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     if constexpr (S == 0) {
@@ -490,10 +503,10 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
                         // phase increments, two samples per packed instruction (v_pk_mul_f32,
                         // v_pk_add_f32, v_pk_mul_f32: the reference's mul, add, mul, unfused)
                         v2f_t inc[U / 2];
-                        if constexpr (SPLIT > 0 && S == SPLIT) { // handed over by the front wavefront
+                        if constexpr (CONSUMES) { // handed over by the wavefront of the stage in front
 #pragma unroll
                             for (int u = 0; u < U; u += 4) {
-                                const float4 q = xbuf[(Q * (U / 4) + u / 4) * kWave + lane];
+                                const float4 q = xin[(Q * (U / 4) + u / 4) * kWave + lane];
                                 inc[u / 2] = v2f_t{q.x, q.y}, inc[u / 2 + 1] = v2f_t{q.z, q.w};
                             }
                         } else {
@@ -509,12 +522,13 @@ __global__ __launch_bounds__((HELP ? 4 : 1) * kSynthWaves * kWave) void k_synth(
                         }
                     }
                 }
-                if constexpr (SPLIT > 0 && S == SPLIT - 1) { // front: hand operator SPLIT's increments over
+                if constexpr (PRODUCES) { // hand the next operator's increments over
+                    constexpr int NX = S + 1 < OPS ? S + 1 : S;
 #pragma unroll
                     for (int u = 0; u < U; u += 4) {
-                        const v2f_t lo = (v2f_t{T[S][Q][0][u], T[S][Q][0][u + 1]} * mul[SPLIT][0] + off[SPLIT][0]) * c;
-                        const v2f_t hi = (v2f_t{T[S][Q][0][u + 2], T[S][Q][0][u + 3]} * mul[SPLIT][0] + off[SPLIT][0]) * c;
-                        xbuf[(Q * (U / 4) + u / 4) * kWave + lane] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                        const v2f_t lo = (v2f_t{T[S][Q][0][u], T[S][Q][0][u + 1]} * mul[NX][0] + off[NX][0]) * c;
+                        const v2f_t hi = (v2f_t{T[S][Q][0][u + 2], T[S][Q][0][u + 3]} * mul[NX][0] + off[NX][0]) * c;
+                        xout[(Q * (U / 4) + u / 4) * kWave + lane] = make_float4(lo.x, lo.y, hi.x, hi.y);
                     }
                 }
             };
@@ -2085,7 +2099,13 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     switch (kind) {
         SOTS_SYNTH_CASE(SOTS_SYNTH_2OP, 1)
         SOTS_SYNTH_CASE(SOTS_SYNTH_3OP_SERIES, 2)
-        SOTS_SYNTH_CASE(SOTS_SYNTH_4OP_SERIES, 2)
+    case SOTS_SYNTH_4OP_SERIES:
+        // up to 64 individuals per CU cut twice - operators {0, 1} | {2} | {3}, three wavefronts on three SIMDs (190 against
+        // 215 us at P = 16384, N = 4096); with two groups per CU six wavefronts would share four SIMDs (279 against 258)
+        if (cut && waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 2, false, 3><<<grid, 3 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        else if (cut) k_synth<SOTS_SYNTH_4OP_SERIES, 2><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        else k_synth<SOTS_SYNTH_4OP_SERIES, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        break;
     case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); break;
     default: return hipErrorInvalidValue;
     }
