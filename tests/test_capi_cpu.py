@@ -81,3 +81,24 @@ def test_no_cpu_fallback_without_a_gpu(hip):
     assert rc == -3 and not h.value
     with pytest.raises(hip.SotsError):
         hip.HipES(16, 16, 0, 10, None, [3520.0, 8.0, 3520.0, 1.0])
+
+
+def test_group_create_validates_without_a_gpu(hip):
+    """sots_group_create checks its arguments before it touches a device; without a gfx950 device a valid request
+    fails with SOTS_ERR_NO_DEVICE like sots_create (no CPU fallback for islands either)."""
+    lib = hip.load()
+    g = C.c_void_p()
+    one = (C.c_int32 * 1)(0)
+    cfg = _cfg(hip)
+    assert lib.sots_group_create(None, one, 1, 4, 1, 0, C.byref(g)) == -1
+    assert lib.sots_group_create(C.byref(cfg), one, 0, 4, 1, 0, C.byref(g)) == -1 and b"numDevices" in lib.sots_group_last_error(None)
+    many = (C.c_int32 * 17)(*range(17))
+    assert lib.sots_group_create(C.byref(cfg), many, 17, 4, 1, 0, C.byref(g)) == -1
+    assert lib.sots_group_create(C.byref(_cfg(hip, struct_size=8)), one, 1, 4, 1, 0, C.byref(g)) == -1
+    rc = lib.sots_group_create(C.byref(cfg), one, 1, 4, 1, 0, C.byref(g))
+    if rc == 0:      # a GPU is present (the GPU box): a one-island group is fine
+        assert lib.sots_group_size(g) == 1 and not lib.sots_group_uses_rccl(g)
+        lib.sots_group_destroy(g)
+    else:
+        assert rc == -3 and not g.value
+    assert lib.sots_group_size(None) == 0 and lib.sots_group_island(None, 0) is None

@@ -82,6 +82,18 @@ def test_sots_match_cli(tmp_path, O):
     out = subprocess.run([exe, "-j", str(p)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert out.returncode == 0, out.stderr
     assert float(out.stdout.split("Fitness = ")[1].split()[0]) < 3e-2
+    # island model from the JSON block: two islands (sharing device 0), elites every generation
+    cfg["type"]["input"] = "params"
+    cfg["type"]["HIP"].update({"numDevices": 2, "devices": [0, 0], "numElites": 16, "migrationInterval": 1})
+    cfg["general"]["isBenchmarking"] = False
+    p.write_text(json.dumps(cfg))
+    out = subprocess.run([exe, "-j", str(p)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    assert float(out.stdout.split("Fitness = ")[1].split()[0]) < 1e-6
+    rate = float(out.stdout.split("Candidates evaluated per second: ")[1].split()[0])
+    assert rate > 0
+    cfg["type"]["HIP"].update({"numDevices": 1})
+    cfg["type"]["HIP"].pop("devices")
     # wrong implementation is refused
     cfg["type"]["implementation"] = "OpenCL"
     p.write_text(json.dumps(cfg))
