@@ -205,6 +205,12 @@ __device__ __forceinline__ float4 nt_load4(const float4 *p)
 // its order, unfused, so the audio is bit-identical to the serial loop.
 // ------------------------------------------------------------------------------------
 constexpr int kSynthUnroll = 8; // samples per pipeline block
+#ifndef SOTS_SYNTH_UNROLL_CUT
+#define SOTS_SYNTH_UNROLL_CUT 16
+#endif
+// ... and of a chain cut over several wavefronts: a trip there ends in a workgroup barrier and starts with the read of
+// the block handed over (together about 400 cycles), so longer blocks halve the number of trips
+constexpr int kSynthUnrollCut = SOTS_SYNTH_UNROLL_CUT;
 constexpr float kWf = (float)kWavetableSize;
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
@@ -343,7 +349,8 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
                                                                uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
 {
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
-    constexpr int U = kSynthUnroll;
+    constexpr int U = SPLIT > 0 ? kSynthUnrollCut : kSynthUnroll;
+    static_assert(U % 4 == 0 && 4 * kStageChunks % U == 0, "whole 16-byte chunks, whole blocks per flush");
     static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
     static_assert(SPLIT2 == 0 || (SPLIT > 0 && SPLIT2 > SPLIT && SPLIT2 < OPS), "the second cut lies behind the first");
     static_assert(!HELP || (SPLIT == 0 && D == 4), "the helper wavefronts serve the uncut 4-gene voice");
@@ -389,9 +396,10 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
     const bool front = my_stage != STAGES - 1;                  // not the tail: no tile, no stores
     const uint32_t wave = wave_id - rho * pairs;                // which 64 individuals of the workgroup's tile
     float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
-    // hand-over buffers [link][pair][parity][U/4][lane] of 16 bytes behind the (at most two) tiles of a cut kernel
-    float4 *__restrict__ xbuf0 = stage_all + 2 * kWave * kStageChunks + wave * (2 * (U / 4) * kWave);
-    float4 *__restrict__ xbuf1 = xbuf0 + 2 * (2 * (U / 4) * kWave);
+    // hand-over buffers [link][pair][parity][U/4][lane] of 16 bytes behind the tiles of a cut kernel (launch_synth keeps
+    // pairs * (tile + links * hand-over buffer) inside stage_all: two pairs with one link, one pair with two)
+    float4 *__restrict__ xbuf0 = stage_all + pairs * kWave * kStageChunks + wave * (2 * (U / 4) * kWave);
+    float4 *__restrict__ xbuf1 = xbuf0 + pairs * (2 * (U / 4) * kWave);
     // write side: lane = row; chunk q of the row lives in slot q ^ (row & 7)
     float4 *__restrict__ wr = stage + lane * kStageChunks;
     const uint32_t l7 = lane & 7u;
@@ -548,9 +556,9 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
                         y[u] = T[OPS - 1][Q][0][u] * gain[0];
                 }
                 const uint32_t c0 = (ip >> 2) & (kStageChunks - 1);
-                wr[c0 ^ l7] = make_float4(y[0], y[1], y[2], y[3]);
-                wr[(c0 + 1) ^ l7] = make_float4(y[4], y[5], y[6], y[7]);
-                if (c0 == kStageChunks - 2) { // 32 samples parked: flush the tile
+#pragma unroll
+                for (int q = 0; q < U / 4; ++q) wr[(c0 + q) ^ l7] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                if (c0 == kStageChunks - U / 4) { // 32 samples parked: flush the tile
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
                     const uint32_t i0 = ip + U - 4 * kStageChunks;
@@ -1283,6 +1291,7 @@ __global__ __launch_bounds__(wg_threads<LOG2N>()) void k_fitness_wg(const float 
 // ------------------------------------------------------------------------------------
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kSortTile = 4096; // keys per LDS tile (32 KiB)
+constexpr uint32_t kSortSmall = 1024; // populations sorted by one workgroup in one launch (k_sort_small)
 
 __device__ __forceinline__ uint64_t make_key(float f, uint32_t idx)
 {
@@ -1682,6 +1691,71 @@ __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict_
         samples[gridDim.x * kSelSamples + blockIdx.x * kSelSamples + rank / kSelQuantum] = i; // indices behind all the bits
     }
     SOTS_PHASE(11);
+}
+
+// A whole population of at most 1024 rows in ONE launch and one workgroup (the reference's default sizes are this
+// small, and there a launch costs as much as the sort): k_sel_tiles' network - one key per lane, 64-key runs sorted in
+// registers, a key's place = its lane + its lower bounds in the other runs - and then every lane moves the row whose
+// key it ended up with.  Same order as the full sort: fitness, equal fitness by index, NaN last.
+template <uint32_t RUNS>
+__global__ __launch_bounds__(RUNS *kWave) void k_sort_small(const float *__restrict__ vin, const float *__restrict__ sin,
+                                                            const float *__restrict__ fin, float *__restrict__ vout,
+                                                            float *__restrict__ sout, float *__restrict__ fout,
+                                                            uint32_t p_len, uint32_t d, uint32_t first_row)
+{
+    __shared__ uint32_t runs[RUNS * kWave];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    uint32_t b = tid < p_len ? order_bits(fin[tid]) : kSelPadBits, i = tid;
+    bitonic_merge<2, 1>(b, i, lane);
+    bitonic_merge<4, 2>(b, i, lane);
+    bitonic_merge<8, 4>(b, i, lane);
+    bitonic_merge<16, 8>(b, i, lane);
+    bitonic_merge<32, 16>(b, i, lane);
+    bitonic_merge<64, 32>(b, i, lane);
+    // this lane now holds row i's key and moves that row: its first genes are asked for before its place is known
+    const bool real = i < p_len;
+    const uint32_t src = real ? i : 0u;
+    float v4[4], s4[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+        v4[c] = c < d ? vin[src * d + c] : 0.0f;
+        s4[c] = c < d ? sin[src * d + c] : 0.0f;
+    }
+    const float f = fin[src];
+    uint32_t rank = lane;
+    if constexpr (RUNS > 1) {
+        runs[tid] = b;
+        __syncthreads();
+        uint32_t pos[RUNS], thr[RUNS];
+#pragma unroll
+        for (uint32_t w = 0; w < RUNS; ++w) {
+            pos[w] = w * kWave;
+            thr[w] = w == wave ? 0u : b + (w < wave ? 1u : 0u);
+        }
+#pragma unroll
+        for (uint32_t step = kWave / 2; step >= 1; step >>= 1) {
+#pragma unroll
+            for (uint32_t w = 0; w < RUNS; ++w) pos[w] += runs[pos[w] + step - 1] < thr[w] ? step : 0u;
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < RUNS; ++w) rank += pos[w] - w * kWave + (runs[pos[w]] < thr[w] ? 1u : 0u);
+    }
+    if (!real || rank < first_row) return; // padding keys sort behind every row
+    fout[rank] = f;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c)
+        if (c < d) vout[rank * d + c] = v4[c], sout[rank * d + c] = s4[c];
+    for (uint32_t c0 = 4; c0 < d; c0 += 4) { // wider voices: four more genes per trip
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            v4[c] = c0 + c < d ? vin[src * d + c0 + c] : 0.0f;
+            s4[c] = c0 + c < d ? sin[src * d + c0 + c] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c)
+            if (c0 + c < d) vout[rank * d + c0 + c] = v4[c], sout[rank * d + c0 + c] = s4[c];
+    }
 }
 
 // Four neighbouring sorted tiles of 1024 keys -> one sorted tile of 4096 with a sample every 512 keys.  For
@@ -2228,7 +2302,7 @@ static bool sort_two_level(uint32_t n_pad) { return n_pad >= kSortTwoLevelFrom &
 
 static void sort_plan(uint32_t n_pad, uint32_t &tile, uint32_t &tiles)
 {
-    if (n_pad <= kSortTile) tile = n_pad;
+    if (n_pad <= kSortSmall) tile = n_pad; // (k_sort_small: no tiles at all)
     else if (n_pad <= 65536u || sort_two_level(n_pad)) tile = 1024u;
     else tile = kSortTile;
     tiles = n_pad / tile;
@@ -2268,6 +2342,16 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
                        uint32_t d, uint32_t first_row)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    if (n_pad <= kSortSmall) { // one launch
+        switch ((n_pad + kWave - 1) / kWave) {
+        case 1: k_sort_small<1><<<1, 1 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
+        case 2: k_sort_small<2><<<1, 2 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
+        case 4: k_sort_small<4><<<1, 4 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
+        case 8: k_sort_small<8><<<1, 8 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
+        default: k_sort_small<16><<<1, 16 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
+        }
+        return hipGetLastError();
+    }
     uint32_t tile, tiles;
     sort_plan(n_pad, tile, tiles);
     uint32_t threads = tile / 2;
