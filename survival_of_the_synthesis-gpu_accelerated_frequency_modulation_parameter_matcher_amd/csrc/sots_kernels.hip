@@ -342,6 +342,19 @@ template <int V> using ic = std::integral_constant<int, V>;
 // 256 lanes at one; the twelve extra wavefronts then leave and the usual four synthesise.
 // SPLIT2 > SPLIT: a second cut in front of operator SPLIT2 - three wavefronts per 64 individuals (stages of operators
 // [0, SPLIT), [SPLIT, SPLIT2), [SPLIT2, OPS)), two hand-over links; for the 4-operator voice at <= 128 individuals per CU
+// where a series chain of OPS operators is cut, as compile-time facts
+template <int SPLIT, int SPLIT2, int OPS> struct CutPlan {
+    static constexpr int STAGES = 1 + (SPLIT > 0 ? 1 : 0) + (SPLIT2 > 0 ? 1 : 0);
+    // stage of operator S: 0 = the chain's head ... STAGES-1 = its tail (which also owns the tile)
+    static constexpr int stage_of(int S) { return SPLIT == 0 ? 0 : S < SPLIT ? 0 : (SPLIT2 > 0 && S >= SPLIT2) ? 2 : 1; }
+    // In trip k operator S works on block k - slot(S): one trip behind the operator in front of it, TWO behind it
+    // across a cut (the stage in front sends a block in the trip AFTER it read the table for it, when the values
+    // have landed, and the block is read in the trip after that); block k - slot(OPS) leaves.
+    static constexpr int slot(int S) { return S + (SPLIT > 0 && S >= SPLIT ? 1 : 0) + (SPLIT2 > 0 && S >= SPLIT2 ? 1 : 0); }
+    static constexpr bool consumes(int S) { return SPLIT > 0 && S > 0 && (S == SPLIT || S == SPLIT2); }
+    static constexpr bool produces(int S) { return SPLIT > 0 && S + 1 < OPS && (S + 1 == SPLIT || S + 1 == SPLIT2); }
+};
+
 template <int KIND, int SPLIT, bool HELP = false, int SPLIT2 = 0>
 __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(const float *__restrict__ values,
                                                                const float *__restrict__ wavetable,
@@ -354,9 +367,8 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
     static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
     static_assert(SPLIT2 == 0 || (SPLIT > 0 && SPLIT2 > SPLIT && SPLIT2 < OPS), "the second cut lies behind the first");
     static_assert(!HELP || (SPLIT == 0 && D == 4), "the helper wavefronts serve the uncut 4-gene voice");
-    constexpr int STAGES = 1 + (SPLIT > 0 ? 1 : 0) + (SPLIT2 > 0 ? 1 : 0);
-    // stage of operator S: 0 = the chain's head ... STAGES-1 = its tail (which also owns the tile)
-    auto stage_of = [](int S) constexpr { return SPLIT == 0 ? 0 : S < SPLIT ? 0 : (SPLIT2 > 0 && S >= SPLIT2) ? 2 : 1; };
+    using Plan = CutPlan<SPLIT, SPLIT2, OPS>;
+    constexpr int STAGES = Plan::STAGES;
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
     request_wavetable(tab, wavetable);
@@ -407,6 +419,9 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
     const uint32_t r8 = lane >> 3;
     const float4 *__restrict__ rd = stage + r8 * kStageChunks + (l7 ^ r8);
     const uint32_t lane_off = r8 * pitch + 4u * l7; // floats, relative to the group's first row
+    uint32_t row_off[8];                            // ... and, in BYTES, of this lane's line in each of the eight groups of 8 rows
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) row_off[g] = (lane_off + g * 8u * pitch) * 4u; // < 2^32: 64 rows of at most 8224 floats
 
     const uint32_t rows_per_block = pairs * kWave;
     float help_next[HELP ? D : 1]; // HELP: the second tile's values
@@ -479,31 +494,67 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
         }
         SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave_id);
 
-        auto run = [&](auto unclamped_tag) {
+        auto run = [&](auto unclamped_tag, auto stage_tag) {
             constexpr bool UNCLAMPED = decltype(unclamped_tag)::value;
+            constexpr int MY = decltype(stage_tag)::value; // this wavefront's stage, a compile-time fact in here: its loop holds
+                                                          // (and keeps registers for) its own operators only
             float pos[OPS][J];
 #pragma unroll
             for (int o = 0; o < OPS; ++o)
 #pragma unroll
                 for (int j = 0; j < J; ++j) pos[o][j] = 0.0f;
             float T[OPS][2][J][U]; // table values of operator s, block parity, chain, sample
+            v2f_t handed[U / 2];   // cut kernels: the increments fetched for this wavefront's first operator
+            v2f_t to_hand[U / 2];  // ... and the ones made for the next stage's
 
-            // operator S on the block of parity Q
-            auto op = [&](auto s_tag, auto q_tag) {
-                constexpr int S = decltype(s_tag)::value, Q = decltype(q_tag)::value;
-                if constexpr (SPLIT > 0) {
-                    if (stage_of(S) != my_stage) return; // another wavefront's operator
+            // Schedule (CutPlan): operator S works on block k - slot(S) in trip k.  A block's parity (which half of T,
+            // which hand-over buffer) is its index & 1.
+            // link = the producer's stage: operators [0, SPLIT) send through xbuf0, [SPLIT, SPLIT2) through xbuf1
+            auto link_of = [&](int producer) -> float4 * { return (SPLIT2 > 0 && producer >= SPLIT) ? xbuf1 : xbuf0; };
+
+            // the increments of operator S's block (parity B), asked for at the start of the trip
+            auto fetch = [&](auto s_tag, auto b_tag) {
+                constexpr int S = decltype(s_tag)::value, B = decltype(b_tag)::value;
+                if constexpr (Plan::consumes(S) && Plan::stage_of(S) == MY) {
+                    const float4 *__restrict__ xin = link_of(S - 1);
+#pragma unroll
+                    for (int u = 0; u < U; u += 4) {
+                        const float4 q = xin[(B * (U / 4) + u / 4) * kWave + lane];
+                        handed[u / 2] = v2f_t{q.x, q.y}, handed[u / 2 + 1] = v2f_t{q.z, q.w};
+                    }
                 }
-                constexpr bool CONSUMES = SPLIT > 0 && S > 0 && stage_of(S) != stage_of(S - 1);
-                constexpr bool PRODUCES = SPLIT > 0 && S + 1 < OPS && stage_of(S + 1) != stage_of(S);
-                float4 *__restrict__ xin = (S > 0 && stage_of(S > 0 ? S - 1 : 0) == 1) ? xbuf1 : xbuf0;  // link = the producer's stage
-                float4 *__restrict__ xout = stage_of(S) == 1 ? xbuf1 : xbuf0;
+            };
+            // operator S + 1's increments from operator S's block of parity B (read from the table one trip ago):
+            // c * (t * mul + off), the reference's mul, add, mul, unfused, two samples per packed instruction
+            auto make_handover = [&](auto s_tag, auto b_tag) {
+                constexpr int S = decltype(s_tag)::value, B = decltype(b_tag)::value;
+                if constexpr (Plan::produces(S) && Plan::stage_of(S) == MY) {
+                    constexpr int NX = S + 1 < OPS ? S + 1 : S;
+#pragma unroll
+                    for (int u = 0; u < U; u += 2)
+                        to_hand[u / 2] = (v2f_t{T[S][B][0][u], T[S][B][0][u + 1]} * mul[NX][0] + off[NX][0]) * c;
+                }
+            };
+            auto send_handover = [&](auto s_tag, auto b_tag) {
+                constexpr int S = decltype(s_tag)::value, B = decltype(b_tag)::value;
+                if constexpr (Plan::produces(S) && Plan::stage_of(S) == MY) {
+                    float4 *__restrict__ xout = link_of(S);
+#pragma unroll
+                    for (int u = 0; u < U; u += 4)
+                        xout[(B * (U / 4) + u / 4) * kWave + lane] =
+                            make_float4(to_hand[u / 2].x, to_hand[u / 2].y, to_hand[u / 2 + 1].x, to_hand[u / 2 + 1].y);
+                }
+            };
+            // operator S on its block of parity B
+            auto op = [&](auto s_tag, auto b_tag) {
+                constexpr int S = decltype(s_tag)::value, B = decltype(b_tag)::value;
+                if constexpr (Plan::stage_of(S) == MY) // else: another wavefront's operator
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     if constexpr (S == 0) {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            T[0][Q][j][u] = tab_at<!UNCLAMPED>(tab, pos[0][j]);
+                            T[0][B][j][u] = tab_at<!UNCLAMPED>(tab, pos[0][j]);
                             pos[0][j] += inc0[j];
                             wrap_hi(pos[0][j]);
                         }
@@ -511,113 +562,143 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
                         // phase increments, two samples per packed instruction (v_pk_mul_f32,
                         // v_pk_add_f32, v_pk_mul_f32: the reference's mul, add, mul, unfused)
                         v2f_t inc[U / 2];
-                        if constexpr (CONSUMES) { // handed over by the wavefront of the stage in front
+                        if constexpr (Plan::consumes(S)) { // handed over by the wavefront of the stage in front
 #pragma unroll
-                            for (int u = 0; u < U; u += 4) {
-                                const float4 q = xin[(Q * (U / 4) + u / 4) * kWave + lane];
-                                inc[u / 2] = v2f_t{q.x, q.y}, inc[u / 2 + 1] = v2f_t{q.z, q.w};
-                            }
+                            for (int u = 0; u < U; u += 2) inc[u / 2] = handed[u / 2];
                         } else {
 #pragma unroll
                             for (int u = 0; u < U; u += 2)
-                                inc[u / 2] = (v2f_t{T[S - 1][Q][j][u], T[S - 1][Q][j][u + 1]} * mul[S][j] + off[S][j]) * c;
+                                inc[u / 2] = (v2f_t{T[S - 1][B][j][u], T[S - 1][B][j][u + 1]} * mul[S][j] + off[S][j]) * c;
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            T[S][Q][j][u] = tab_at(tab, pos[S][j]);
+                            T[S][B][j][u] = tab_at(tab, pos[S][j]);
                             pos[S][j] += (u & 1) ? inc[u / 2].y : inc[u / 2].x;
                             wrap_both(pos[S][j]);
                         }
                     }
                 }
-                if constexpr (PRODUCES) { // hand the next operator's increments over
-                    constexpr int NX = S + 1 < OPS ? S + 1 : S;
+            };
+            // a tile on its way out: eight rows x 128-byte lines per store instruction, the address a wavefront-uniform
+            // line start plus a per-lane offset that never changes (no vector address arithmetic per flush)
+            float pend[8][4]; // (plain floats: an array of float4 does not leave memory for registers)
+            float *__restrict__ pend_line = audio;
+            bool pending = false;
+            auto store_pending = [&]() {
+                if constexpr (MY != STAGES - 1) return;
+                if (!pending) return;
+                pending = false;
 #pragma unroll
-                    for (int u = 0; u < U; u += 4) {
-                        const v2f_t lo = (v2f_t{T[S][Q][0][u], T[S][Q][0][u + 1]} * mul[NX][0] + off[NX][0]) * c;
-                        const v2f_t hi = (v2f_t{T[S][Q][0][u + 2], T[S][Q][0][u + 3]} * mul[NX][0] + off[NX][0]) * c;
-                        xout[(Q * (U / 4) + u / 4) * kWave + lane] = make_float4(lo.x, lo.y, hi.x, hi.y);
-                    }
+                for (int g = 0; g < 8; ++g) {
+                    asm volatile("" : "+v"(row_off[g])); // the zero-extension stays next to the store: scalar base + 32-bit lane offset
+                    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(pend_line) + row_off[g]) = make_float4(pend[g][0], pend[g][1], pend[g][2], pend[g][3]);
                 }
             };
-            // samples ip..ip+7 (the block of parity Q) leave
-            auto emit = [&](auto q_tag, uint32_t ip) {
-                constexpr int Q = decltype(q_tag)::value;
-                if constexpr (SPLIT > 0) {
-                    if (front) return;
-                }
+            // samples ip..ip+U-1 (the block of parity B) leave
+            auto emit = [&](auto b_tag, uint32_t ip) {
+                constexpr int B = decltype(b_tag)::value;
+                if constexpr (MY != STAGES - 1) return; // only the tail stage has samples
                 float y[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if constexpr (KIND == SOTS_SYNTH_TRIPLE_PAR)
-                        y[u] = (T[OPS - 1][Q][0][u] * gain[0] + T[OPS - 1][Q][1][u] * gain[1] + T[OPS - 1][Q][2][u] * gain[2]) /
+                        y[u] = (T[OPS - 1][B][0][u] * gain[0] + T[OPS - 1][B][1][u] * gain[1] + T[OPS - 1][B][2][u] * gain[2]) /
                                3.0f; // == (float)(double(sum)/3.0), :493
                     else
-                        y[u] = T[OPS - 1][Q][0][u] * gain[0];
+                        y[u] = T[OPS - 1][B][0][u] * gain[0];
                 }
+                store_pending(); // the tile read back one trip ago leaves now: its LDS reads have long landed
                 const uint32_t c0 = (ip >> 2) & (kStageChunks - 1);
 #pragma unroll
                 for (int q = 0; q < U / 4; ++q) wr[(c0 + q) ^ l7] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+#ifdef SOTS_ABL_NOFLUSH
+                if (false) {
+#else
                 if (c0 == kStageChunks - U / 4) { // 32 samples parked: flush the tile
+#endif
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
                     const uint32_t i0 = ip + U - 4 * kStageChunks;
-                    float *__restrict__ grp = audio + (size_t)row0 * pitch + i0 + lane_off;
+                    float *__restrict__ line0 = audio + (size_t)row0 * pitch + i0; // wavefront-uniform
                     if (full) {
+                        // read back transposed now (LDS works in order: the next samples are parked behind these
+                        // reads), stored in the next trip
                         constexpr int G = 8 * kStageChunks; // slots per group of 8 rows
-                        const float4 q0 = rd[0 * G], q1 = rd[1 * G], q2 = rd[2 * G], q3 = rd[3 * G];
-                        const float4 q4 = rd[4 * G], q5 = rd[5 * G], q6 = rd[6 * G], q7 = rd[7 * G];
-                        const size_t g8 = (size_t)8u * pitch;
-                        *reinterpret_cast<float4 *>(grp + 0 * g8) = q0;
-                        *reinterpret_cast<float4 *>(grp + 1 * g8) = q1;
-                        *reinterpret_cast<float4 *>(grp + 2 * g8) = q2;
-                        *reinterpret_cast<float4 *>(grp + 3 * g8) = q3;
-                        *reinterpret_cast<float4 *>(grp + 4 * g8) = q4;
-                        *reinterpret_cast<float4 *>(grp + 5 * g8) = q5;
-                        *reinterpret_cast<float4 *>(grp + 6 * g8) = q6;
-                        *reinterpret_cast<float4 *>(grp + 7 * g8) = q7;
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            const float4 q = rd[g * G];
+                            pend[g][0] = q.x, pend[g][1] = q.y, pend[g][2] = q.z, pend[g][3] = q.w;
+                        }
+                        pend_line = line0;
+                        pending = true;
                     } else { // last, partly filled tile of the population
 #pragma unroll 1
                         for (uint32_t it = 0; it < kWave / 8; ++it)
                             if (row0 + 8u * it + r8 < p_len)
-                                *reinterpret_cast<float4 *>(grp + (size_t)(8u * it) * pitch) = rd[it * 8 * kStageChunks];
+                                *reinterpret_cast<float4 *>(line0 + lane_off + (size_t)(8u * it) * pitch) = rd[it * 8 * kStageChunks];
                     }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
                 }
             };
-            // Trip k of parity Q: operator s works on block k - s (parity Q ^ (s & 1)) for
-            // s in [SMIN, min(SMAX, OPS-1)], and block k - OPS leaves when SMAX == OPS.
-            auto trip = [&](auto q_tag, auto smin_tag, auto smax_tag, uint32_t k) {
-                constexpr int Q = decltype(q_tag)::value, SMIN = decltype(smin_tag)::value, SMAX = decltype(smax_tag)::value;
-                if constexpr (SMIN <= 0 && 0 <= SMAX) op(ic<0>{}, ic<Q>{});
-                if constexpr (SMIN <= 1 && 1 <= SMAX && 1 < OPS) op(ic<1>{}, ic<Q ^ 1>{});
-                if constexpr (SMIN <= 2 && 2 <= SMAX && 2 < OPS) op(ic<2>{}, ic<Q>{});
-                if constexpr (SMIN <= 3 && 3 <= SMAX && 3 < OPS) op(ic<3>{}, ic<Q ^ 1>{});
-                if constexpr (SMAX == OPS) emit(ic<Q ^ (OPS & 1)>{}, (k - OPS) * U);
-                if constexpr (SPLIT > 0) __syncthreads(); // the block handed over in this trip is read in the next
+            const uint32_t nb = n / U; // even and >= 32
+            constexpr int LAST = Plan::slot(OPS); // the slot in which a block leaves
+            // Trip k of parity Q.  EDGE (the first and last trips): a slot only works while its block index lies in
+            // [0, nb).  Cut kernels: what a wavefront waits for from another stage is asked for first, work that does
+            // not need it comes next (the hand-over arithmetic of the block read one trip ago, the samples that leave),
+            // then the operators; the hand-over is written last, and only a wavefront that wrote one waits for its LDS
+            // operations before the barrier (the tail stage keeps its table reads in flight across it).
+            auto trip = [&](auto q_tag, auto edge_tag, uint32_t k) {
+                constexpr int Q = decltype(q_tag)::value;
+                constexpr bool EDGE = decltype(edge_tag)::value;
+                auto on = [&](int sl) { return !EDGE || (k >= (uint32_t)sl && k - (uint32_t)sl < nb); };
+                auto each_op = [&](auto &&f, auto shift_tag) { // f(S, parity of the block of slot(S) + shift) where that block exists
+                    constexpr int SH = decltype(shift_tag)::value;
+                    if (on(Plan::slot(0) + SH)) f(ic<0>{}, ic<(Q ^ ((Plan::slot(0) + SH) & 1))>{});
+                    if constexpr (OPS > 1) if (on(Plan::slot(1) + SH)) f(ic<1>{}, ic<(Q ^ ((Plan::slot(1) + SH) & 1))>{});
+                    if constexpr (OPS > 2) if (on(Plan::slot(2) + SH)) f(ic<2>{}, ic<(Q ^ ((Plan::slot(2) + SH) & 1))>{});
+                    if constexpr (OPS > 3) if (on(Plan::slot(3) + SH)) f(ic<3>{}, ic<(Q ^ ((Plan::slot(3) + SH) & 1))>{});
+                };
+                if constexpr (SPLIT > 0) {
+                    each_op(fetch, ic<0>{});
+                    each_op(make_handover, ic<1>{}); // the block this operator read the table for one trip ago
+                    if (on(LAST)) emit(ic<(Q ^ (LAST & 1))>{}, (k - LAST) * U);
+                    each_op(op, ic<0>{});
+                    each_op(send_handover, ic<1>{});
+                    asm volatile("" ::: "memory");
+#ifndef SOTS_ABL_NOBARRIER
+                    if constexpr (MY != STAGES - 1) __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the hand-over is in LDS
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    asm volatile("" ::: "memory");
+                } else {
+                    each_op(op, ic<0>{});
+                    if (on(LAST)) emit(ic<(Q ^ (LAST & 1))>{}, (k - LAST) * U);
+                }
             };
-            const uint32_t nb = n / U; // even and >= 64
-            constexpr int K0 = (OPS + 1) & ~1; // first trip with every stage busy, rounded to even
-            // fill: trip k runs operators 0..min(k, OPS) - the stage index OPS is the emit
-            trip(ic<0>{}, ic<0>{}, ic<0>{}, 0);
-            trip(ic<1>{}, ic<0>{}, ic<1>{}, 1);
-            if constexpr (K0 > 2) {
-                trip(ic<0>{}, ic<0>{}, ic<2>{}, 2);
-                trip(ic<1>{}, ic<0>{}, ic<(OPS < 3 ? OPS : 3)>{}, 3);
+            constexpr uint32_t K0 = (LAST + 1) & ~1; // first trip with every slot busy, rounded to even
+            for (uint32_t k = 0; k < K0; k += 2) {
+                trip(ic<0>{}, std::true_type{}, k);
+                trip(ic<1>{}, std::true_type{}, k + 1);
             }
             for (uint32_t k = K0; k < nb; k += 2) {
-                trip(ic<0>{}, ic<0>{}, ic<OPS>{}, k);
-                trip(ic<1>{}, ic<0>{}, ic<OPS>{}, k + 1);
+                trip(ic<0>{}, std::false_type{}, k);
+                trip(ic<1>{}, std::false_type{}, k + 1);
             }
-            // drain: trip nb + j runs stages j+1..OPS
-            trip(ic<0>{}, ic<1>{}, ic<OPS>{}, nb);
-            trip(ic<1>{}, ic<2>{}, ic<OPS>{}, nb + 1);
-            if constexpr (OPS > 2) trip(ic<0>{}, ic<3>{}, ic<OPS>{}, nb + 2);
-            if constexpr (OPS > 3) trip(ic<1>{}, ic<4>{}, ic<OPS>{}, nb + 3);
+            for (uint32_t k = nb; k < nb + K0; k += 2) { // the last block leaves in trip nb - 1 + LAST
+                trip(ic<0>{}, std::true_type{}, k);
+                trip(ic<1>{}, std::true_type{}, k + 1);
+            }
+            store_pending();
         };
-        if (free_unclamped) run(std::true_type{});
-        else run(std::false_type{});
+        auto run_my_stage = [&](auto unclamped_tag) {
+            if constexpr (STAGES == 1) run(unclamped_tag, ic<0>{});
+            else if (my_stage == 0) run(unclamped_tag, ic<0>{});
+            else if (STAGES == 2 || my_stage == 1) run(unclamped_tag, ic<1>{});
+            else run(unclamped_tag, ic<(STAGES > 2 ? 2 : 0)>{});
+        };
+        if (free_unclamped) run_my_stage(std::true_type{});
+        else run_my_stage(std::false_type{});
     }
     if (table_pending) wavetable_ready(); // a workgroup without a tile must not end with copies in flight
 }
