@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -20,8 +21,10 @@ using namespace sots;
 namespace {
 
 struct StageClock {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // recorded, not yet read
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> spare;
+    // recorded, not yet read.  Inside the fused generation loop consecutive stages SHARE the event between them (the
+    // end of one is the start of the next: one event record per kernel boundary instead of two), so an event may
+    // sit in two pairs; events are owned by the context's pool and go back to it once every clock has been read.
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0.0;
     uint64_t count = 0;
     std::vector<float> launches_ms; // per-launch durations since the last reset (bounded: kMaxLaunchSamples)
@@ -68,6 +71,8 @@ struct sots_ctx {
     float window_factor = 1.0f, inv_n = 0.0f, inv_wf = 1.0f;
     // timing
     bool timing = false;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t chain_tail = nullptr; // fused loop: the event the last stage ended with
     StageClock clocks[SOTS_STAGE_COUNT];
     mutable std::string err;
     char arch[32] = {0};
@@ -125,46 +130,77 @@ int bind_device(const sots_ctx *ctx)
 }
 
 // ---- stage timing -------------------------------------------------------------------
+hipEvent_t take_event(sots_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// CHAIN (the fused generation loop, where the stages follow each other on the stream with nothing in between): the
+// stage starts at the event the stage before it ended with.
 struct StageScope {
     sots_ctx *ctx;
     StageClock *clock = nullptr;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    StageScope(sots_ctx *c, int stage) : ctx(c)
+    bool chain;
+    StageScope(sots_ctx *c, int stage, bool chained = false) : ctx(c), chain(chained)
     {
         if (!c->timing) return;
-        clock = &c->clocks[stage];
-        if (!clock->spare.empty()) {
-            ev = clock->spare.back();
-            clock->spare.pop_back();
+        if (chain && c->chain_tail) {
+            ev.first = c->chain_tail;
         } else {
-            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
-                clock = nullptr;
-                return;
-            }
+            ev.first = take_event(c);
+            if (ev.first) (void)hipEventRecord(ev.first, c->stream);
         }
-        (void)hipEventRecord(ev.first, c->stream);
+        ev.second = take_event(c);
+        if (!ev.first || !ev.second) { // (a lost pair costs a sample, nothing else)
+            if (ev.first && ev.first != c->chain_tail) c->event_pool.push_back(ev.first);
+            if (ev.second) c->event_pool.push_back(ev.second);
+            return;
+        }
+        clock = &c->clocks[stage];
     }
     ~StageScope()
     {
         if (!clock) return;
         (void)hipEventRecord(ev.second, ctx->stream);
         clock->pending.push_back(ev);
+        if (chain) ctx->chain_tail = ev.second;
     }
 };
 
-int drain_clock(sots_ctx *ctx, StageClock &ck)
+// reads every recorded pair of every stage and returns the events to the pool
+int drain_clocks(sots_ctx *ctx)
 {
-    for (auto &ev : ck.pending) {
-        SOTS_HIP(ctx, hipEventSynchronize(ev.second));
-        float ms = 0.0f;
-        SOTS_HIP(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
-        ck.total_ms += ms;
-        ck.count += 1;
-        if (ck.launches_ms.size() < kMaxLaunchSamples) ck.launches_ms.push_back(ms);
-        ck.spare.push_back(ev);
+    std::vector<hipEvent_t> used;
+    int rc = SOTS_OK;
+    for (auto &ck : ctx->clocks) {
+        for (auto &ev : ck.pending) {
+            used.push_back(ev.first);
+            used.push_back(ev.second);
+            if (rc) continue;
+            float ms = 0.0f;
+            if (hipEventSynchronize(ev.second) != hipSuccess || hipEventElapsedTime(&ms, ev.first, ev.second) != hipSuccess) {
+                rc = fail(ctx, SOTS_ERR_HIP, "stage timing: %s", hipGetErrorString(hipGetLastError()));
+                continue;
+            }
+            ck.total_ms += ms;
+            ck.count += 1;
+            if (ck.launches_ms.size() < kMaxLaunchSamples) ck.launches_ms.push_back(ms);
+        }
+        ck.pending.clear();
     }
-    ck.pending.clear();
-    return SOTS_OK;
+    std::sort(used.begin(), used.end());
+    used.erase(std::unique(used.begin(), used.end()), used.end());
+    ctx->event_pool.insert(ctx->event_pool.end(), used.begin(), used.end());
+    ctx->chain_tail = nullptr;
+    return rc;
 }
 
 // keep the number of live events bounded on long runs
@@ -172,10 +208,7 @@ int maybe_drain(sots_ctx *ctx)
 {
     if (!ctx->timing) return SOTS_OK;
     for (auto &ck : ctx->clocks)
-        if (ck.pending.size() >= 4096) {
-            int rc = drain_clock(ctx, ck);
-            if (rc) return rc;
-        }
+        if (ck.pending.size() >= 4096) return drain_clocks(ctx);
     return SOTS_OK;
 }
 
@@ -184,9 +217,13 @@ void free_ctx(sots_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto &ck : ctx->clocks) {
-        for (auto &ev : ck.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-        for (auto &ev : ck.spare) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    {
+        std::vector<hipEvent_t> all = ctx->event_pool;
+        for (auto &ck : ctx->clocks)
+            for (auto &ev : ck.pending) all.push_back(ev.first), all.push_back(ev.second);
+        std::sort(all.begin(), all.end());
+        all.erase(std::unique(all.begin(), all.end()), all.end());
+        for (hipEvent_t e : all) (void)hipEventDestroy(e);
     }
     void *bufs[] = {ctx->values, ctx->steps, ctx->fitness, ctx->audio, ctx->spectrum, ctx->target,
                     ctx->wavetable, ctx->window, ctx->rows, ctx->twiddle, ctx->keys, ctx->sort_scratch};
@@ -680,6 +717,7 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         // the variation below overwrites the unsorted half a pending tail would be completed from; nobody has
         // asked for those rows, so they are dropped
         ctx->tail_pending = false;
+        ctx->chain_tail = nullptr; // (the caller may have put other work on the stream since the last generation)
         uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
         // Large populations of 4-gene individuals make their individuals inside the synthesis kernel
         // (one launch less, 151 vs 157 us per generation at P = 65536); with few wavefronts per CU or
@@ -687,13 +725,13 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         const bool fuse_variation = ctx->fuse_variation >= 0 ? ctx->fuse_variation == 1
                                                              : (ctx->pd.d <= 4 && ctx->P >= 192u * (ctx->num_cus ? ctx->num_cus : 256u));
         if (!fuse_variation) {
-            StageScope t(ctx, SOTS_STAGE_FUSED_VARIATION);
+            StageScope t(ctx, SOTS_STAGE_FUSED_VARIATION, true);
             SOTS_HIP(ctx, launch_recombine_mutate(ctx->stream, ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst),
                                                   ctx->pd, ctx->mc, ctx->generation));
         }
         ctx->rot = dst;
         if (ctx->skip_stage != 1) {
-            StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH);
+            StageScope t(ctx, SOTS_STAGE_FUSED_SYNTH, true);
             // raw synthesis (the window is applied by the FFT kernel as it loads the row); by default the
             // kernel also makes its individuals: recombination + mutation from the sorted half
             sots::Variation var = {ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst), ctx->pd, ctx->mc, ctx->generation};
@@ -702,14 +740,14 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
                                        fuse_variation ? &var : nullptr, ctx->allow_cut));
         }
         if (ctx->skip_stage != 2) {
-            StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL);
+            StageScope t(ctx, SOTS_STAGE_FUSED_SPECTRAL, true);
             SOTS_HIP(ctx, launch_fft_fitness(ctx->stream, ctx->audio, ctx->window, ctx->target, ctx->fit(ctx->rot), ctx->twiddle, ctx->P,
                                              ctx->log2n, ctx->pitch, ctx->inv_n, ctx->inv_wf, ctx->num_cus, &ctx->occ));
         }
         src = ctx->rot;
         dst = ctx->rot ^ 1u;
         {
-            StageScope t(ctx, SOTS_STAGE_SORT);
+            StageScope t(ctx, SOTS_STAGE_SORT, true);
             if (select) {
                 // the rows recombination reads, in order; the rest of the order is produced on demand
                 SOTS_HIP(ctx, launch_select(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst),
@@ -764,8 +802,8 @@ int sots_timing_reset(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
     if (int rc = bind_device(ctx)) return rc;
+    if (int rc = drain_clocks(ctx)) return rc;
     for (auto &ck : ctx->clocks) {
-        if (int rc = drain_clock(ctx, ck)) return rc;
         ck.total_ms = 0.0;
         ck.count = 0;
         ck.launches_ms.clear();
@@ -778,7 +816,7 @@ int sots_stage_time_ms(sots_ctx *ctx, int stage, double *total_ms, uint64_t *cou
     SOTS_REQUIRE_CTX(ctx);
     if (stage < 0 || stage >= SOTS_STAGE_COUNT) return fail(ctx, SOTS_ERR_INVALID, "stage %d out of range", stage);
     if (int rc = bind_device(ctx)) return rc;
-    if (int rc = drain_clock(ctx, ctx->clocks[stage])) return rc;
+    if (int rc = drain_clocks(ctx)) return rc;
     if (total_ms) *total_ms = ctx->clocks[stage].total_ms;
     if (count) *count = ctx->clocks[stage].count;
     return SOTS_OK;
@@ -790,7 +828,7 @@ int sots_stage_launch_times_ms(sots_ctx *ctx, int stage, float *out_ms, uint64_t
     if (stage < 0 || stage >= SOTS_STAGE_COUNT) return fail(ctx, SOTS_ERR_INVALID, "stage %d out of range", stage);
     if (!written || (capacity && !out_ms)) return fail(ctx, SOTS_ERR_INVALID, "stage_launch_times: null argument");
     if (int rc = bind_device(ctx)) return rc;
-    if (int rc = drain_clock(ctx, ctx->clocks[stage])) return rc;
+    if (int rc = drain_clocks(ctx)) return rc;
     const std::vector<float> &v = ctx->clocks[stage].launches_ms;
     const uint64_t n = v.size() < capacity ? v.size() : capacity;
     for (uint64_t i = 0; i < n; ++i) out_ms[i] = v[i];
