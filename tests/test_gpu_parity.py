@@ -281,11 +281,13 @@ def sort_case(P, rng):
     return f
 
 
-# covers every sort plan: one LDS tile (<= 4096), 1024-key tiles + one rank level (<= 65536, with and
-# without padding keys), 1024-key tiles merged into runs of 8192 + a rank level over the runs (131072
-# to 1M, with and without padding keys), global bitonic fallback (> 1M)
+# covers every sort plan: one launch / one workgroup (<= 1024: 1, 2, 4, 8, 16 runs of 64 keys, with and without
+# padding keys), 1024-key tiles + one rank level (2048 .. 65536, with and without padding keys), 1024-key tiles
+# merged into runs of 8192 + a rank level over the runs (131072 to 1M, with and without padding keys), global
+# bitonic fallback (> 1M)
 @pytest.mark.parametrize("parents,offspring,block", [
-    (16, 16, 32), (64, 192, 32), (24, 72, 32), (256, 768, 32), (1024, 3072, 32), (2048, 6144 + 32, 32),
+    (16, 16, 32), (64, 192, 32), (24, 72, 32), (32, 96, 32), (128, 384, 32), (248, 744, 32), (256, 768, 32),
+    (512, 1536, 32), (704, 2304, 32), (1024, 3072, 32), (2048, 6144 + 32, 32),
     (16384, 49152, 32), (32768, 98304, 32), (40000, 110016, 32), (65536, 196608, 32), (262144, 786432, 32),
     (262144, 786432 + 32, 32)])
 def test_sort_matches_stable_oracle(pkg, O, parents, offspring, block):
@@ -304,6 +306,23 @@ def test_sort_matches_stable_oracle(pkg, O, parents, offspring, block):
     assert np.array_equal(gf, f[perm], equal_nan=True)
     assert np.array_equal(gv, v[perm])
     assert np.array_equal(gs, s[perm])
+    es.close()
+
+
+@pytest.mark.parametrize("kind,log2n", [(1, 10), (3, 10), (2, 10)])
+def test_small_sort_moves_wide_rows(pkg, O, kind, log2n):
+    """the one-launch sort moves four genes per trip: voices with 6, 8 and 12 genes, a population with padding keys"""
+    es, _ = make_pair(pkg, O, 96, 288, kind, log2n)
+    rng = np.random.default_rng(kind)
+    P, D = es.P, es.D
+    f = sort_case(P, rng)
+    v = rng.random((P, D), dtype=np.float32)
+    s = rng.random((P, D), dtype=np.float32)
+    es.write_population(v, s, f)
+    es.sort(); es.rotate()
+    gv, gs, gf = es.read_population()
+    perm = O.sort_perm(f)
+    assert np.array_equal(gf, f[perm], equal_nan=True) and np.array_equal(gv, v[perm]) and np.array_equal(gs, s[perm])
     es.close()
 
 
