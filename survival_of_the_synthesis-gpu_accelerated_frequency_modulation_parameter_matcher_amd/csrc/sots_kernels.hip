@@ -1222,9 +1222,14 @@ __global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) vo
 {
     constexpr int N = 1 << LOG2N, M = N / 2, T = wg_threads<LOG2N>(), E = M / T, H = E / 2, W = T / kWave;
     static_assert(M == 1024 || M == 2048 || M == 4096, "workgroup-per-row FFT is for N >= 2048");
-    __shared__ float2 lds[M + M / 8 + 1];
+    // Two exchange buffers, used alternately by the four passes: a pass writes the buffer the pass before it did NOT
+    // read from, so one barrier per exchange (written -> read) is enough; with one buffer every exchange needs a second
+    // barrier (read -> overwritten), and a workgroup barrier costs a few hundred cycles at two or three workgroups per CU.
+    // The wavefront sums alternate the same way per row, so the last barrier of a row is its fourth pass's.
+    constexpr int LDS_ROW = M + M / 8 + 1;
+    __shared__ float2 lds2[2 * LDS_ROW];
     __shared__ float tgt_s[MODE == 1 ? M + 1 : 1];
-    __shared__ float red[W];
+    __shared__ float red[2][W];
     const int tid = threadIdx.x;
     const float half_scale = 0.5f * (inv_n * inv_wf); // the split below leaves a factor of two in
     if constexpr (MODE == 1) {
@@ -1260,6 +1265,8 @@ __global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) vo
         for (int sl = 0; sl < E; ++sl) x[sl] = in[tid + T * sl];
     }
     __syncthreads(); // target spectrum in place
+    uint32_t prev = 0xFFFFFFFFu; // the row whose wavefront sums wait in red[parity ^ 1]
+    int parity = 0;
     while (true) {
         if constexpr (WIN) {
 #pragma unroll
@@ -1272,21 +1279,38 @@ __global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) vo
 #pragma unroll
             for (int sl = 0; sl < E; ++sl) y[sl] = in[tid + T * sl];
         }
-#define SOTS_WG_PASS(R, NS, OFF)                                              \
-    wg_pass<M, R, NS, T>(x, lds, tw, TWR ? &twr[OFF] : nullptr, tid);         \
+        // pass i writes buffer i & 1 (the row before left its Z in buffer 1 and every wavefront has passed this row's ... see
+        // the barrier notes below); SOTS_WG_NEXT reads the buffer just written
+#define SOTS_WG_PASS(R, NS, OFF, BUF)                                                   \
+    wg_pass<M, R, NS, T>(x, lds2 + (BUF) * LDS_ROW, tw, TWR ? &twr[OFF] : nullptr, tid); \
     __syncthreads();
-#define SOTS_WG_NEXT()                                                        \
-    _Pragma("unroll") for (int sl = 0; sl < E; ++sl) x[sl] = lds[lds_pad(tid + T * sl)]; \
-    __syncthreads();
+#define SOTS_WG_PREV() /* behind B1: the row before this one is complete */             \
+    if constexpr (MODE == 1) {                                                          \
+        if (tid == 0 && prev != 0xFFFFFFFFu) {                                          \
+            float total = red[parity ^ 1][0];                                           \
+            _Pragma("unroll") for (int w = 1; w < W; ++w) total += red[parity ^ 1][w];  \
+            fitness[prev] = total;                                                      \
+        }                                                                               \
+    }
+#define SOTS_WG_NEXT(BUF)                                                               \
+    _Pragma("unroll") for (int sl = 0; sl < E; ++sl) x[sl] = lds2[(BUF) * LDS_ROW + lds_pad(tid + T * sl)];
         if constexpr (M == 1024) {
-            SOTS_WG_PASS(8, 1, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 8, 0) SOTS_WG_NEXT() SOTS_WG_PASS(4, 64, 7) SOTS_WG_NEXT() SOTS_WG_PASS(4, 256, 13)
+            SOTS_WG_PASS(8, 1, 0, 0) SOTS_WG_PREV() SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 8, 0, 1) SOTS_WG_NEXT(1) SOTS_WG_PASS(4, 64, 7, 0) SOTS_WG_NEXT(0) SOTS_WG_PASS(4, 256, 13, 1)
         } else if constexpr (M == 2048) {
-            SOTS_WG_PASS(8, 1, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 8, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 64, 7) SOTS_WG_NEXT() SOTS_WG_PASS(4, 512, 14)
+            SOTS_WG_PASS(8, 1, 0, 0) SOTS_WG_PREV() SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 8, 0, 1) SOTS_WG_NEXT(1) SOTS_WG_PASS(8, 64, 7, 0) SOTS_WG_NEXT(0) SOTS_WG_PASS(4, 512, 14, 1)
         } else {
-            SOTS_WG_PASS(8, 1, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 8, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 64, 0) SOTS_WG_NEXT() SOTS_WG_PASS(8, 512, 0)
+            SOTS_WG_PASS(8, 1, 0, 0) SOTS_WG_PREV() SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 8, 0, 1) SOTS_WG_NEXT(1) SOTS_WG_PASS(8, 64, 0, 0) SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 512, 0, 1)
         }
 #undef SOTS_WG_PASS
+#undef SOTS_WG_PREV
 #undef SOTS_WG_NEXT
+        // Hazards, with one barrier behind each pass's writes (B1..B4):  buffer 0 is written by passes 1 and 3, read
+        // after B1 and after B3; pass 3's writes come after B2, which every wavefront reaches only after its reads
+        // behind B1.  Buffer 1 is written by passes 2 and 4 and read after B2 and after B4 (the split below); pass 2 of
+        // the NEXT row writes it after that row's B1, which a wavefront reaches only after this row's split.  Pass 1 of
+        // the next row writes buffer 0, last read behind B3.  The wavefront sums of row r sit in red[r & 1], written
+        // after B4(r) and read by thread 0 after B1(r+1) (the last row: after a barrier of its own).
+        const float2 *__restrict__ lds = lds2 + LDS_ROW;
         // Z is in LDS in natural order.  Split and error for k = tid + T q (and its mirror M - k)
         const float2 zh = lds[lds_pad(M / 2)];
         const float2 x_half = make_float2(zh.x, -zh.y); // bin M/2
@@ -1311,20 +1335,22 @@ __global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) vo
             if (tid == 0) row[M / 2] = x_half;
         } else {
             acc = wave_sum(acc);
-            if ((tid & (kWave - 1)) == 0) red[tid / kWave] = acc;
-        }
-        __syncthreads(); // Z consumed (next row may overwrite it); wavefront sums in place
-        if constexpr (MODE == 1) {
-            if (tid == 0) {
-                float total = red[0];
-#pragma unroll
-                for (int w = 1; w < W; ++w) total += red[w];
-                fitness[ind] = total;
-            }
+            if ((tid & (kWave - 1)) == 0) red[parity][tid / kWave] = acc;
         }
         if (!more) break;
         for (int sl = 0; sl < E; ++sl) x[sl] = y[sl];
+        prev = ind;
         ind = nxt;
+        parity ^= 1;
+    }
+    if constexpr (MODE == 1) {
+        __syncthreads(); // the last row's wavefront sums
+        if (tid == 0) {
+            float total = red[parity][0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) total += red[parity][w];
+            fitness[ind] = total;
+        }
     }
 }
 
