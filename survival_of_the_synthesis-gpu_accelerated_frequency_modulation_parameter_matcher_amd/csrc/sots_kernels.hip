@@ -2177,6 +2177,325 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
 }
 
 // ------------------------------------------------------------------------------------
+// Batched real FFT + fitness for N = 4096 (and 2048) WITHOUT LDS exchanges: one wavefront per row,
+// E = N/128 complex points per lane in registers, the 64-point sub-transforms ACROSS lanes.
+//
+// The workgroup-per-row kernel above makes four dependent LDS round trips per row behind workgroup
+// barriers, with 8 wavefronts per CU (0.40 of the HBM roofline at N = 4096).  Here a row never leaves
+// the registers of its wavefront.  With M = 64 E complex points z[n], n = l + 64 j (lane l, register j):
+//   Z[q + E p] = sum_l W_64^{l p} ( W_M^{l q} sum_j z[l + 64 j] W_E^{j q} )
+//   1. an E-point DFT over j inside every lane (radix-2 DIF in registers; register r ends with q = bitrev(r));
+//   2. the twiddle W_M^{l q};
+//   3. for every register a 64-point DFT over the LANES: six radix-2 DIF stages whose partner lane is l ^ h,
+//      h = 32, 16, 8, 4, 2, 1 - v_permlane32_swap, ds_swizzle (LDS crossbar, no LDS memory), DPP row rotate,
+//      DPP quad permutes - a lane with bit h clear keeps a + b, the other one (a - b) W_2h^{l mod h}
+//      (both as fma(own, +-1, partner) times a per-lane constant).  Lane l ends with p = bitrev6(l).
+// So lane l, register r holds Z[k], k = bitrev(r) + E bitrev6(l): E consecutive bins per lane.  The real-input
+// split needs Z[M - k]: register bitrev(E - q) of lane l ^ 63 (q >= 1) - one ds_bpermute per dword - and every
+// lane turns its own E bins into squared errors (no pair is computed twice).  Window, step-2 twiddles, split
+// twiddles and target are laid out per (lane, register) in LDS once per workgroup (61 KiB, read as 16-byte words).
+// ------------------------------------------------------------------------------------
+#pragma clang fp contract(on)
+constexpr int x_bitrev(int v, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+template <int LOG2N> constexpr int x_points() { return (1 << LOG2N) / 2 / kWave; }
+#ifndef SOTS_X_WAVES12
+#define SOTS_X_WAVES12 12
+#endif
+template <int LOG2N> constexpr int x_waves() { return LOG2N >= 12 ? SOTS_X_WAVES12 : 12; } // wavefronts (independent rows) per workgroup
+template <int LOG2N> constexpr bool x_applies() { return LOG2N == 11 || LOG2N == 12; }
+
+// f(ic<I>{}) for I = FIRST .. LAST-1 with I a compile-time constant inside f (register arrays are indexed with it)
+template <int FIRST, int LAST, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (FIRST < LAST) {
+        f(ic<FIRST>{});
+        static_for<FIRST + 1, LAST>(f);
+    }
+}
+
+// Complex values are 2-vectors here (register pairs): the transform is VALU-bound (85 % busy at 2400 one-float
+// instructions per row in its first form), and v_pk_add/mul/fma_f32 do a complex add, or half a complex multiply, per
+// instruction.
+#ifndef SOTS_X_NT
+#define SOTS_X_NT 1
+#endif
+__device__ __forceinline__ v2f_t x_row_load(const float2 *p)
+{
+#if SOTS_X_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(p)); // rows are read once
+#else
+    return *reinterpret_cast<const v2f_t *>(p);
+#endif
+}
+__device__ __forceinline__ v2f_t xv(float2 a) { return v2f_t{a.x, a.y}; }
+// a * w: (a.x, a.y) * w.x + (-a.y, a.x) * w.y - a packed multiply and a packed fma (operand selects and negations are
+// instruction modifiers)
+__device__ __forceinline__ v2f_t xc_mul(v2f_t a, v2f_t w)
+{
+    const v2f_t t = a * __builtin_shufflevector(w, w, 0, 0);
+    const v2f_t ar = __builtin_shufflevector(a, a, 1, 0);
+    const v2f_t wy = __builtin_shufflevector(w, w, 1, 1);
+    return ar * v2f_t{-wy.x, wy.y} + t;
+}
+__device__ __forceinline__ v2f_t xc_mul_neg_i(v2f_t a) { return v2f_t{a.y, -a.x}; }
+
+// one radix-2 DIF stage of the E-point transform over the registers: pairs (a, a + H) inside groups of 2 H
+template <int H, int E, int N>
+__device__ __forceinline__ void x_reg_stage(v2f_t (&x)[E], const float2 *__restrict__ tw)
+{
+    static_for<0, E / 2>([&](auto i_tag) {
+        constexpr int I = decltype(i_tag)::value, A0 = (I / H) * 2 * H, A = A0 + I % H;
+        constexpr int IDX = (A - A0) * (E / (2 * H)); // the twiddle is W_E^IDX
+        const v2f_t u = x[A] + x[A + H], d = x[A] - x[A + H];
+        x[A] = u;
+        if constexpr (IDX == 0) x[A + H] = d;
+        else if constexpr (IDX == E / 4) x[A + H] = xc_mul_neg_i(d);
+        else x[A + H] = xc_mul(d, xv(tw[IDX * (N / E)]));
+    });
+    if constexpr (H > 1) x_reg_stage<H / 2, E, N>(x, tw);
+}
+
+template <uint32_t J> __device__ __forceinline__ float lane_xor_f(float v)
+{
+    if constexpr (J == 8) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true)); // row_ror:8
+    else return __uint_as_float(lane_xor<J>(__float_as_uint(v)));
+}
+
+// one radix-2 DIF stage over the lanes, partner l ^ H, on every register: own * (+-1) + partner, times the lane's
+// constant (1 where bit H is clear)
+template <uint32_t H, int E>
+__device__ __forceinline__ void x_lane_stage(v2f_t (&x)[E], float sgn, v2f_t wl)
+{
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const v2f_t p = v2f_t{lane_xor_f<H>(x[r].x), lane_xor_f<H>(x[r].y)};
+        const v2f_t t = x[r] * v2f_t{sgn, sgn} + p;
+        x[r] = H == 1 ? t : xc_mul(t, wl);
+        if (r % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The stages with partner l ^ 32 and l ^ 16 take the registers two at a time: v_permlane32_swap / v_permlane16_swap
+// (new in gfx950) exchange the upper half (odd rows of 16) of one register with the lower half (even rows) of the other, so
+// after swapping A with B the lanes with bit H clear hold BOTH inputs of register A's butterfly and the others both
+// inputs of B's; every lane computes one whole butterfly (sum, difference times W_2H^{l mod H}) and a second pair of
+// swaps puts the results where they belong.  Four swaps and four packed operations per pair of complex values, no
+// per-lane signs, no select.
+template <uint32_t H>
+__device__ __forceinline__ void x_swap2(v2f_t &a, v2f_t &b)
+{
+    if constexpr (H == 32) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+        a = v2f_t{__uint_as_float(r0[0]), __uint_as_float(r1[0])}, b = v2f_t{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+    } else {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+        a = v2f_t{__uint_as_float(r0[0]), __uint_as_float(r1[0])}, b = v2f_t{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+    }
+}
+template <uint32_t H, int E>
+__device__ __forceinline__ void x_lane_stage_pairs(v2f_t (&x)[E], v2f_t w)
+{
+#pragma unroll
+    for (int r = 0; r < E; r += 2) {
+        x_swap2<H>(x[r], x[r + 1]);
+        v2f_t sum = x[r] + x[r + 1], dif = xc_mul(x[r] - x[r + 1], w);
+        x_swap2<H>(sum, dif);
+        x[r] = sum, x[r + 1] = dif;
+        if (r % 8 == 6) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int LOG2N, int MODE, bool WIN>
+__global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
+                                                                   const float *__restrict__ target, float *__restrict__ fitness,
+                                                                   const float2 *__restrict__ tw, const float *__restrict__ window,
+                                                                   uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 16 ? 4 : 5), W = x_waves<LOG2N>();
+    constexpr int S2 = E + 2, S1 = E + 4; // lane strides of the float2 / float tables (16-byte reads, spread over the banks)
+    __shared__ __attribute__((aligned(16))) float2 tw2_s[kWave * S2], tws_s[kWave * S2], win_s[WIN ? kWave * S2 : 1];
+    __shared__ __attribute__((aligned(16))) float tgt_s[MODE == 1 ? kWave * S1 : 4];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    for (uint32_t e = tid; e < kWave * E; e += W * kWave) {
+        const uint32_t l = e / E, r = e % E;
+        const uint32_t q = __brev(r) >> (32 - EB), pp = __brev(l) >> 26, k = q + E * pp;
+        tw2_s[l * S2 + r] = tw[2u * l * q]; // W_M^{l q} = W_N^{2 l q}
+        tws_s[l * S2 + r] = tw[k];          // W_N^k
+        if constexpr (WIN) win_s[l * S2 + r] = reinterpret_cast<const float2 *>(window)[l + kWave * r]; // r = input register j here
+        if constexpr (MODE == 1) tgt_s[l * S1 + r] = target[k];
+    }
+    // per-lane constants of the six lane stages
+    const float sg8 = (lane & 8u) ? -1.0f : 1.0f;
+    const float sg4 = (lane & 4u) ? -1.0f : 1.0f, sg2 = (lane & 2u) ? -1.0f : 1.0f, sg1 = (lane & 1u) ? -1.0f : 1.0f;
+    const v2f_t one = v2f_t{1.0f, 0.0f};
+    const v2f_t w32 = xv(tw[(lane & 31u) * (N / 64)]), w16 = xv(tw[(lane & 15u) * (N / 32)]); // (every lane makes a difference there)
+    const v2f_t w8 = (lane & 8u) ? xv(tw[(lane & 7u) * (N / 16)]) : one, w4 = (lane & 4u) ? xv(tw[(lane & 3u) * (N / 8)]) : one;
+    const v2f_t w2 = (lane & 2u) ? xv(tw[(lane & 1u) * (N / 4)]) : one;
+    const uint32_t pp = __brev(lane) >> 26;
+    const int addr_flip = (int)((lane ^ 63u) * 4u);                        // partner lane of the registers with q >= 1
+    const int addr_zero = (int)((__brev((64u - pp) & 63u) >> 26) * 4u);    // ... and of register 0 (q = 0): Z[E (64 - p)]
+    const float half_scale = 0.5f * (inv_n * inv_wf);
+    __syncthreads();
+
+    // rows: wavefront w of workgroup b takes b W + w, then every (grid W)-th
+    uint32_t row = blockIdx.x * W + wave;
+    if (row >= p_len) return;
+    v2f_t x[E];
+    {
+        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)row * pitch);
+#pragma unroll
+        for (int j = 0; j < E; ++j) x[j] = x_row_load(in + lane + kWave * j);
+    }
+    while (true) {
+        const uint32_t nxt = row + gridDim.x * W;
+        const bool more = nxt < p_len;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WIN) {
+#pragma unroll
+            for (int j = 0; j < E; j += 2) {
+                const float4 wv = *reinterpret_cast<const float4 *>(&win_s[lane * S2 + j]);
+                x[j] = x[j] * v2f_t{wv.x, wv.y};
+                x[j + 1] = x[j + 1] * v2f_t{wv.z, wv.w};
+                if (j % 8 == 6) __builtin_amdgcn_sched_barrier(0); // (table reads a few at a time: the row already fills 2 E registers)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // 1. E-point DIF over the registers
+        x_reg_stage<E / 2, E, N>(x, tw);
+        __builtin_amdgcn_sched_barrier(0);
+        // 2. W_M^{l q}
+#pragma unroll
+        for (int r = 0; r < E; r += 2) {
+            const float4 t = *reinterpret_cast<const float4 *>(&tw2_s[lane * S2 + r]);
+            if (r) x[r] = xc_mul(x[r], v2f_t{t.x, t.y}); // register 0: q = 0
+            x[r + 1] = xc_mul(x[r + 1], v2f_t{t.z, t.w});
+            if (r % 8 == 6) __builtin_amdgcn_sched_barrier(0);
+        }
+        // 3. 64-point DIF over the lanes
+        x_lane_stage_pairs<32>(x, w32);
+        __builtin_amdgcn_sched_barrier(0);
+        x_lane_stage_pairs<16>(x, w16);
+        __builtin_amdgcn_sched_barrier(0);
+        x_lane_stage<8>(x, sg8, w8);
+        __builtin_amdgcn_sched_barrier(0);
+        x_lane_stage<4>(x, sg4, w4);
+        __builtin_amdgcn_sched_barrier(0);
+        x_lane_stage<2>(x, sg2, w2);
+        __builtin_amdgcn_sched_barrier(0);
+        x_lane_stage<1>(x, sg1, one);
+        __builtin_amdgcn_sched_barrier(0);
+        // split: this lane's E bins k = bitrev(r) + E p
+        float acc = 0.0f;
+        v2f_t out_even = v2f_t{0.f, 0.f}; // MODE 0: bins leave two at a time, in bin order
+        float2 *__restrict__ dst = MODE == 0 ? reinterpret_cast<float2 *>(spectrum + (size_t)row * (N + 8)) + E * pp : nullptr;
+        // one bin: register RR of this lane with its partner Z[M - k]
+        auto bin2x = [&](auto r_tag) -> v2f_t {
+            constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
+            const int addr = Q == 0 ? addr_zero : addr_flip;
+            const v2f_t zm = v2f_t{__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x[R2].x))),
+                                   __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x[R2].y)))};
+            const v2f_t w = xv(tws_s[lane * S2 + RR]);
+            const v2f_t b = v2f_t{zm.x, -zm.y};
+            const v2f_t ee = x[RR] + b, dd = x[RR] - b;
+            return ee + xc_mul(xc_mul_neg_i(dd), w); // 2 X[k] = (Z[k] + conj Z[M-k]) + W_N^k (-i) (Z[k] - conj Z[M-k])
+        };
+        if constexpr (MODE == 1) {
+            // Registers RR and R2 = bitrev(E - bitrev(RR)) need each other and nobody else: the bins are taken in such
+            // pairs (this is the summation order, k_fitness_x repeats it), and a pair that is done is free - the NEXT
+            // row's loads into those two registers go out at once, so by the end of the split most of the next row is on
+            // its way without a second set of registers.
+            const float2 *__restrict__ in_next = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : row) * pitch);
+            static_for<0, E>([&](auto r_tag) {
+                constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
+                if constexpr (R2 >= RR) {
+                    const v2f_t xa = bin2x(ic<RR>{});
+                    acc += bin_error(make_float2(xa.x, xa.y), tgt_s[lane * S1 + RR], half_scale);
+                    if constexpr (R2 != RR) {
+                        const v2f_t xb = bin2x(ic<R2>{});
+                        acc += bin_error(make_float2(xb.x, xb.y), tgt_s[lane * S1 + R2], half_scale);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef SOTS_X_RECYCLE
+#define SOTS_X_RECYCLE 1
+#endif
+                    if constexpr (SOTS_X_RECYCLE != 0) {
+                        x[RR] = x_row_load(in_next + lane + kWave * RR);
+                        if constexpr (R2 != RR) x[R2] = x_row_load(in_next + lane + kWave * R2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            });
+        } else
+        static_for<0, E>([&](auto i_tag) {
+            // MODE 0 walks the bins in order
+            constexpr int I = decltype(i_tag)::value, RR = MODE == 0 ? x_bitrev(I, EB) : I;
+            constexpr int Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
+            const int addr = Q == 0 ? addr_zero : addr_flip;
+            const v2f_t zm = v2f_t{__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x[R2].x))),
+                                   __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x[R2].y)))};
+            const v2f_t w = xv(tws_s[lane * S2 + RR]);
+            // 2 X[k] = (Z[k] + conj Z[M-k]) + W_N^k (-i) (Z[k] - conj Z[M-k])
+            const v2f_t b = v2f_t{zm.x, -zm.y};
+            const v2f_t ee = x[RR] + b, dd = x[RR] - b;
+            const v2f_t x2 = ee + xc_mul(xc_mul_neg_i(dd), w);
+            if constexpr (MODE == 0) {
+                if constexpr (Q % 2 == 0) out_even = x2 * v2f_t{0.5f, 0.5f};
+                else *reinterpret_cast<float4 *>(dst + Q - 1) = make_float4(out_even.x, out_even.y, 0.5f * x2.x, 0.5f * x2.y);
+            } else {
+                acc += bin_error(make_float2(x2.x, x2.y), tgt_s[lane * S1 + RR], half_scale);
+            }
+            if constexpr (I % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (MODE == 0) {
+            // the Nyquist bin X[M] = Re Z0 - Im Z0, from Z0 itself: lane 0 still holds it in register 0
+            if (lane == 0) reinterpret_cast<float2 *>(spectrum + (size_t)row * (N + 8))[M] = make_float2(x[0].x - x[0].y, 0.0f);
+        } else {
+            acc = wave_sum(acc);
+            if (lane == 0) fitness[row] = acc;
+        }
+        if (!more) break;
+        if constexpr (MODE == 0 || SOTS_X_RECYCLE == 0) { // (MODE 1 has asked for the row already, pair by pair)
+            const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)nxt * pitch);
+            static_for<0, E>([&](auto j_tag) { x[decltype(j_tag)::value] = x_row_load(in + lane + kWave * decltype(j_tag)::value); });
+        }
+        row = nxt;
+    }
+}
+
+// fitnessPopulation on materialised rows with k_fft_x's bin -> (lane, register) map and summation order
+template <int LOG2N>
+__global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fitness_x(const float *__restrict__ spectrum, const float *__restrict__ target,
+                                                                       float *__restrict__ fitness, uint32_t p_len, float inv_n, float inv_wf)
+{
+    constexpr int N = 1 << LOG2N, E = x_points<LOG2N>(), EB = (E == 16 ? 4 : 5), W = x_waves<LOG2N>();
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t pp = __brev(lane) >> 26;
+    for (uint32_t row = blockIdx.x * W + wave; row < p_len; row += gridDim.x * W) {
+        const float2 *__restrict__ src = reinterpret_cast<const float2 *>(spectrum + (size_t)row * (N + 8)) + E * pp;
+        float acc = 0.0f;
+        static_for<0, E>([&](auto r_tag) { // k_fft_x's order: register pairs (RR, R2 = bitrev(E - bitrev(RR)))
+            constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
+            if constexpr (R2 >= RR) {
+                acc += bin_error(src[Q], target[E * pp + Q], inv_n * inv_wf);
+                if constexpr (R2 != RR) acc += bin_error(src[x_bitrev(R2, EB)], target[E * pp + x_bitrev(R2, EB)], inv_n * inv_wf);
+            }
+        });
+        acc = wave_sum(acc);
+        if (lane == 0) fitness[row] = acc;
+    }
+}
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------
 // island exchange: rows of [fitness, values, steps]
 // ------------------------------------------------------------------------------------
 __global__ void k_pack_rows(const float *__restrict__ values, const float *__restrict__ steps,
@@ -2336,10 +2655,30 @@ static constexpr uint32_t wg_from() { return 11; }
     default: return hipErrorInvalidValue; \
     }
 
+#ifndef SOTS_FFT_X
+#define SOTS_FFT_X 1
+#endif
+// N = 2048 and 4096 run on the wavefront-per-row kernels with the sub-transforms across lanes (k_fft_x, k_fitness_x)
+static bool x_from(uint32_t log2n) { return SOTS_FFT_X != 0 && (log2n == 11 || log2n == 12); }
+#define SOTS_DISPATCH_X(log2n, CALL)      \
+    switch (log2n) {                      \
+    case 11: { CALL(11); break; }         \
+    case 12: { CALL(12); break; }         \
+    default: return hipErrorInvalidValue; \
+    }
+#define SOTS_X_GRID(K, L) resident_grid(K, x_waves<L>() * kWave, (p + x_waves<L>() - 1) / x_waves<L>(), num_cus, &occ_x[L])
+
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus, OccCache *oc)
 {
     int *occ = oc->fft, *occ_wg = oc->fft_wg;
+    if (x_from(log2n)) {
+        int *occ_x = oc->x_fft;
+#define CALL(L) k_fft_x<L, 0, false><<<SOTS_X_GRID((k_fft_x<L, 0, false>), L), x_waves<L>() * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
+        SOTS_DISPATCH_X(log2n, CALL)
+#undef CALL
+        return hipGetLastError();
+    }
     if (log2n >= wg_from()) {
 #define CALL(L) k_fft_wg<L, 0, false><<<resident_grid(k_fft_wg<L, 0, false>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
         SOTS_DISPATCH_WG(log2n, CALL)
@@ -2356,6 +2695,13 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
     int *occ = oc->fitness, *occ_wg = oc->fitness_wg;
+    if (x_from(log2n)) {
+        int *occ_x = oc->x_fitness;
+#define CALL(L) k_fitness_x<L><<<SOTS_X_GRID(k_fitness_x<L>, L), x_waves<L>() * kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
+        SOTS_DISPATCH_X(log2n, CALL)
+#undef CALL
+        return hipGetLastError();
+    }
     if (log2n >= wg_from()) {
 #define CALL(L) k_fitness_wg<L><<<resident_grid(k_fitness_wg<L>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
         SOTS_DISPATCH_WG(log2n, CALL)
@@ -2373,6 +2719,20 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
                               float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
     int *occ_w = oc->fused_win, *occ_n = oc->fused_raw, *occ_wgw = oc->fused_wg_win, *occ_wgn = oc->fused_wg_raw;
+    if (x_from(log2n)) {
+        if (window) {
+            int *occ_x = oc->x_fused_win;
+#define CALL(L) k_fft_x<L, 1, true><<<SOTS_X_GRID((k_fft_x<L, 1, true>), L), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+            SOTS_DISPATCH_X(log2n, CALL)
+#undef CALL
+        } else {
+            int *occ_x = oc->x_fused_raw;
+#define CALL(L) k_fft_x<L, 1, false><<<SOTS_X_GRID((k_fft_x<L, 1, false>), L), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
+            SOTS_DISPATCH_X(log2n, CALL)
+#undef CALL
+        }
+        return hipGetLastError();
+    }
     if (log2n >= wg_from()) {
         if (window) {
 #define CALL(L) k_fft_wg<L, 1, true><<<resident_grid(k_fft_wg<L, 1, true>, wg_threads<L>(), p, num_cus, &occ_wgw[L]), wg_threads<L>(), 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
