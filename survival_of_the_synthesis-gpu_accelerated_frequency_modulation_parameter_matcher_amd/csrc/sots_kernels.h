@@ -51,8 +51,7 @@ struct Variation {
 // CONTEXT: a context belongs to one device and is used from one thread at a time, so the cache
 // needs no synchronisation (a process-wide cache would be shared by every device and thread).
 struct OccCache {
-    int fft[16], fft_wg[16], fitness[16], fitness_wg[16];
-    int fused_win[16], fused_raw[16], fused_wg_win[16], fused_wg_raw[16];
+    int fft[16], fitness[16], fused_win[16], fused_raw[16];
     int x_fft[16], x_fitness[16], x_fused_win[16], x_fused_raw[16];
 };
 

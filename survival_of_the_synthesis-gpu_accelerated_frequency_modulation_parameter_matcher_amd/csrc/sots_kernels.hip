@@ -1002,7 +1002,7 @@ __device__ __forceinline__ float wave_sum(float v)
 // MODE 0: write spectrum rows; MODE 1: accumulate the fitness directly
 // WIN: multiply by the fp32 window while loading (the generation loop then skips the window
 // pass; the product is the same single fp32 rounding either way).
-// Rows of N <= 1024 only (longer rows: k_fft_wg below).
+// Rows of N <= 1024 only (longer rows: k_fft_x).
 template <int LOG2N, int MODE, bool WIN>
 __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                const float *__restrict__ target, float *__restrict__ fitness,
@@ -1153,238 +1153,6 @@ __global__ __launch_bounds__(kWave) void k_fitness(const float *__restrict__ spe
         }
         acc = wave_sum(acc);
         if (lane == 0) fitness[ind] = acc;
-    }
-}
-
-// ---- long rows: one WORKGROUP per row --------------------------------------------------------
-// From N = 4096 a row no longer fits one wavefront's registers next to a prefetched row (the
-// wavefront-per-row kernel runs one wavefront per SIMD there, and spills at N = 8192).  Here T
-// threads share a row, M / T complex points each, so a thread holds 8 or 16 points and four
-// wavefronts per SIMD stay resident.  Same Stockham passes and real-input split; slot s of a
-// thread is element t + T s, loaded 8 bytes per thread (coalesced), exchanges through the padded
-// LDS buffer with workgroup barriers.  The fitness sum adds the wavefronts' DPP sums in wavefront
-// order; k_fitness_wg, the stage-separated twin, uses the same bin -> thread map and order, so the
-// fused and the stage-separated loop still give bit-identical fitness.
-template <int LOG2N> constexpr int wg_threads() { return LOG2N <= 11 ? 128 : 256; }
-
-template <int M, int R, int NS, int T>
-__device__ __forceinline__ void wg_pass(float2 (&x)[M / T], float2 *__restrict__ lds, const float2 *__restrict__ tw,
-                                        const float2 *twr, int tid)
-{
-    constexpr int E = M / T, B = E / R;
-    static_assert(E % R == 0, "radix must divide the per-thread element count");
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int j = tid + T * b;
-        const int k = j & (NS - 1);
-        float2 v[R];
-#pragma unroll
-        for (int t = 0; t < R; ++t) v[t] = x[b + t * B];
-        if constexpr (NS > 1) {
-            constexpr int stride = (2 * M) / (NS * R);
-#pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], twr ? twr[b * (R - 1) + t - 1] : tw[t * k * stride]);
-        }
-        Dft<R>::run(v);
-        const int j0 = (j - k) * R + k;
-#pragma unroll
-        for (int t = 0; t < R; ++t) lds[lds_pad(j0 + t * NS)] = v[t];
-    }
-}
-
-template <int M, int R, int NS, int T>
-__device__ __forceinline__ void wg_pass_twiddles(float2 *twr, const float2 *__restrict__ tw, int tid)
-{
-    constexpr int E = M / T, B = E / R, stride = (2 * M) / (NS * R);
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int k = (tid + T * b) & (NS - 1);
-#pragma unroll
-        for (int t = 1; t < R; ++t) twr[b * (R - 1) + t - 1] = tw[t * k * stride];
-    }
-}
-
-// per-thread pass twiddles kept in registers (M = 4096 would need 42 complex values: from the table)
-template <int M> constexpr int wg_tw_count() { return M == 1024 ? 19 : M == 2048 ? 20 : 1; }
-
-// minimum wavefronts per SIMD asked of the register allocator: N = 2048 fits 168 registers (three);
-// the longer rows lose more to spills than they gain (measured), so they are left alone
-template <int LOG2N> constexpr int wg_waves_per_simd() { return LOG2N <= 11 ? 3 : 1; }
-
-template <int LOG2N, int MODE, bool WIN>
-__global__ __launch_bounds__(wg_threads<LOG2N>(), wg_waves_per_simd<LOG2N>()) void k_fft_wg(const float *__restrict__ audio,
-                                                                float *__restrict__ spectrum,
-                                                                const float *__restrict__ target,
-                                                                float *__restrict__ fitness,
-                                                                const float2 *__restrict__ tw,
-                                                                const float *__restrict__ window, uint32_t p_len,
-                                                                float inv_n, float inv_wf, uint32_t pitch)
-{
-    constexpr int N = 1 << LOG2N, M = N / 2, T = wg_threads<LOG2N>(), E = M / T, H = E / 2, W = T / kWave;
-    static_assert(M == 1024 || M == 2048 || M == 4096, "workgroup-per-row FFT is for N >= 2048");
-    // Two exchange buffers, used alternately by the four passes: a pass writes the buffer the pass before it did NOT
-    // read from, so one barrier per exchange (written -> read) is enough; with one buffer every exchange needs a second
-    // barrier (read -> overwritten), and a workgroup barrier costs a few hundred cycles at two or three workgroups per CU.
-    // The wavefront sums alternate the same way per row, so the last barrier of a row is its fourth pass's.
-    constexpr int LDS_ROW = M + M / 8 + 1;
-    __shared__ float2 lds2[2 * LDS_ROW];
-    __shared__ float tgt_s[MODE == 1 ? M + 1 : 1];
-    __shared__ float red[2][W];
-    const int tid = threadIdx.x;
-    const float half_scale = 0.5f * (inv_n * inv_wf); // the split below leaves a factor of two in
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) tgt_s[tid + T * q] = target[tid + T * q];
-    }
-    float2 w_split[H], wv[WIN ? E : 1];
-#pragma unroll
-    for (int q = 0; q < H; ++q) w_split[q] = tw[tid + T * q];
-    if constexpr (WIN) {
-#pragma unroll
-        for (int sl = 0; sl < E; ++sl) wv[sl] = reinterpret_cast<const float2 *>(window)[tid + T * sl];
-    }
-    constexpr bool TWR = M <= 2048;
-    float2 twr[wg_tw_count<M>()];
-    if constexpr (M == 1024) {
-        wg_pass_twiddles<M, 8, 8, T>(&twr[0], tw, tid);
-        wg_pass_twiddles<M, 4, 64, T>(&twr[7], tw, tid);
-        wg_pass_twiddles<M, 4, 256, T>(&twr[13], tw, tid);
-    } else if constexpr (M == 2048) {
-        wg_pass_twiddles<M, 8, 8, T>(&twr[0], tw, tid);
-        wg_pass_twiddles<M, 8, 64, T>(&twr[7], tw, tid);
-        wg_pass_twiddles<M, 4, 512, T>(&twr[14], tw, tid);
-    } else {
-        twr[0] = make_float2(0.f, 0.f);
-    }
-    uint32_t ind = blockIdx.x;
-    if (ind >= p_len) return; // whole workgroup
-    float2 x[E], y[E];
-    {
-        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)ind * pitch);
-#pragma unroll
-        for (int sl = 0; sl < E; ++sl) x[sl] = in[tid + T * sl];
-    }
-    __syncthreads(); // target spectrum in place
-    uint32_t prev = 0xFFFFFFFFu; // the row whose wavefront sums wait in red[parity ^ 1]
-    int parity = 0;
-    while (true) {
-        if constexpr (WIN) {
-#pragma unroll
-            for (int sl = 0; sl < E; ++sl) x[sl] = make_float2(x[sl].x * wv[sl].x, x[sl].y * wv[sl].y);
-        }
-        const uint32_t nxt = ind + gridDim.x;
-        const bool more = nxt < p_len;
-        {
-            const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : ind) * pitch);
-#pragma unroll
-            for (int sl = 0; sl < E; ++sl) y[sl] = in[tid + T * sl];
-        }
-        // pass i writes buffer i & 1 (the row before left its Z in buffer 1 and every wavefront has passed this row's ... see
-        // the barrier notes below); SOTS_WG_NEXT reads the buffer just written
-#define SOTS_WG_PASS(R, NS, OFF, BUF)                                                   \
-    wg_pass<M, R, NS, T>(x, lds2 + (BUF) * LDS_ROW, tw, TWR ? &twr[OFF] : nullptr, tid); \
-    __syncthreads();
-#define SOTS_WG_PREV() /* behind B1: the row before this one is complete */             \
-    if constexpr (MODE == 1) {                                                          \
-        if (tid == 0 && prev != 0xFFFFFFFFu) {                                          \
-            float total = red[parity ^ 1][0];                                           \
-            _Pragma("unroll") for (int w = 1; w < W; ++w) total += red[parity ^ 1][w];  \
-            fitness[prev] = total;                                                      \
-        }                                                                               \
-    }
-#define SOTS_WG_NEXT(BUF)                                                               \
-    _Pragma("unroll") for (int sl = 0; sl < E; ++sl) x[sl] = lds2[(BUF) * LDS_ROW + lds_pad(tid + T * sl)];
-        if constexpr (M == 1024) {
-            SOTS_WG_PASS(8, 1, 0, 0) SOTS_WG_PREV() SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 8, 0, 1) SOTS_WG_NEXT(1) SOTS_WG_PASS(4, 64, 7, 0) SOTS_WG_NEXT(0) SOTS_WG_PASS(4, 256, 13, 1)
-        } else if constexpr (M == 2048) {
-            SOTS_WG_PASS(8, 1, 0, 0) SOTS_WG_PREV() SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 8, 0, 1) SOTS_WG_NEXT(1) SOTS_WG_PASS(8, 64, 7, 0) SOTS_WG_NEXT(0) SOTS_WG_PASS(4, 512, 14, 1)
-        } else {
-            SOTS_WG_PASS(8, 1, 0, 0) SOTS_WG_PREV() SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 8, 0, 1) SOTS_WG_NEXT(1) SOTS_WG_PASS(8, 64, 0, 0) SOTS_WG_NEXT(0) SOTS_WG_PASS(8, 512, 0, 1)
-        }
-#undef SOTS_WG_PASS
-#undef SOTS_WG_PREV
-#undef SOTS_WG_NEXT
-        // Hazards, with one barrier behind each pass's writes (B1..B4):  buffer 0 is written by passes 1 and 3, read
-        // after B1 and after B3; pass 3's writes come after B2, which every wavefront reaches only after its reads
-        // behind B1.  Buffer 1 is written by passes 2 and 4 and read after B2 and after B4 (the split below); pass 2 of
-        // the NEXT row writes it after that row's B1, which a wavefront reaches only after this row's split.  Pass 1 of
-        // the next row writes buffer 0, last read behind B3.  The wavefront sums of row r sit in red[r & 1], written
-        // after B4(r) and read by thread 0 after B1(r+1) (the last row: after a barrier of its own).
-        const float2 *__restrict__ lds = lds2 + LDS_ROW;
-        // Z is in LDS in natural order.  Split and error for k = tid + T q (and its mirror M - k)
-        const float2 zh = lds[lds_pad(M / 2)];
-        const float2 x_half = make_float2(zh.x, -zh.y); // bin M/2
-        float acc = 0.0f;
-        float2 *__restrict__ row = MODE == 0 ? reinterpret_cast<float2 *>(spectrum + (size_t)ind * (N + 8)) : nullptr;
-#pragma unroll
-        for (int q = 0; q < H; ++q) {
-            const int k = tid + T * q;
-            float2 xa, xb;
-            if constexpr (MODE == 0) {
-                split_pair(lds[lds_pad(k)], lds[lds_pad((M - k) & (M - 1))], w_split[q], xa, xb);
-                row[k] = xa;
-                row[M - k] = xb; // k = 0 lands on the Nyquist bin M
-            } else {
-                split_pair<false>(lds[lds_pad(k)], lds[lds_pad((M - k) & (M - 1))], w_split[q], xa, xb); // 2 X[k], 2 X[M-k]
-                if (k == 0) xb = make_float2(2.0f * x_half.x, 2.0f * x_half.y); // the fitness skips the Nyquist bin and needs bin M/2
-                acc += bin_error(xa, tgt_s[k], half_scale);
-                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], half_scale);
-            }
-        }
-        if constexpr (MODE == 0) {
-            if (tid == 0) row[M / 2] = x_half;
-        } else {
-            acc = wave_sum(acc);
-            if ((tid & (kWave - 1)) == 0) red[parity][tid / kWave] = acc;
-        }
-        if (!more) break;
-        for (int sl = 0; sl < E; ++sl) x[sl] = y[sl];
-        prev = ind;
-        ind = nxt;
-        parity ^= 1;
-    }
-    if constexpr (MODE == 1) {
-        __syncthreads(); // the last row's wavefront sums
-        if (tid == 0) {
-            float total = red[parity][0];
-#pragma unroll
-            for (int w = 1; w < W; ++w) total += red[parity][w];
-            fitness[ind] = total;
-        }
-    }
-}
-
-// fitnessPopulation on materialised spectrum rows for N >= 2048: the bin -> thread map and the
-// summation order of k_fft_wg<.., 1>
-template <int LOG2N>
-__global__ __launch_bounds__(wg_threads<LOG2N>()) void k_fitness_wg(const float *__restrict__ spectrum,
-                                                                    const float *__restrict__ target,
-                                                                    float *__restrict__ fitness, uint32_t p_len,
-                                                                    float inv_n, float inv_wf)
-{
-    constexpr int N = 1 << LOG2N, M = N / 2, T = wg_threads<LOG2N>(), E = M / T, W = T / kWave;
-    __shared__ float red[W];
-    const int tid = threadIdx.x;
-    for (uint32_t ind = blockIdx.x; ind < p_len; ind += gridDim.x) {
-        const float2 *__restrict__ row = reinterpret_cast<const float2 *>(spectrum + (size_t)ind * (N + 8));
-        float acc = 0.0f;
-#pragma unroll
-        for (int q = 0; q < E / 2; ++q) {
-            const int k = tid + T * q;
-            const int kb = k == 0 ? M / 2 : M - k;
-            acc += bin_error(row[k], target[k], inv_n * inv_wf);
-            acc += bin_error(row[kb], target[kb], inv_n * inv_wf);
-        }
-        acc = wave_sum(acc);
-        if ((tid & (kWave - 1)) == 0) red[tid / kWave] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            float total = red[0];
-#pragma unroll
-            for (int w = 1; w < W; ++w) total += red[w];
-            fitness[ind] = total;
-        }
-        __syncthreads();
     }
 }
 
@@ -2637,9 +2405,8 @@ static uint32_t resident_grid(K kernel, int threads, uint32_t items, uint32_t nu
     return (uint32_t)(items < cap ? items : cap);
 }
 
-// N >= 2048 runs on the workgroup-per-row kernels (k_fft_wg, k_fitness_wg), shorter rows on the
-// wavefront-per-row ones
-static constexpr uint32_t wg_from() { return 11; }
+// N <= 1024 runs on the wavefront-per-row kernels with LDS exchanges (k_fft, k_fitness), longer rows on the
+// wavefront-per-row kernels with the sub-transforms across lanes (k_fft_x, k_fitness_x)
 #define SOTS_DISPATCH_WAVE(log2n, CALL)   \
     switch (log2n) {                      \
     case 9: { CALL(9); break; }           \
@@ -2647,22 +2414,7 @@ static constexpr uint32_t wg_from() { return 11; }
     default: return hipErrorInvalidValue; \
     }
 
-#define SOTS_DISPATCH_WG(log2n, CALL)     \
-    switch (log2n) {                      \
-    case 11: { CALL(11); break; }         \
-    case 12: { CALL(12); break; }         \
-    case 13: { CALL(13); break; }         \
-    default: return hipErrorInvalidValue; \
-    }
-
-#ifndef SOTS_FFT_X
-#define SOTS_FFT_X 1
-#endif
-// N = 2048 and 4096 run on the wavefront-per-row kernels with the sub-transforms across lanes (k_fft_x, k_fitness_x)
-#ifndef SOTS_FFT_X_MAX
-#define SOTS_FFT_X_MAX 13
-#endif
-static bool x_from(uint32_t log2n) { return SOTS_FFT_X != 0 && log2n >= 11 && log2n <= SOTS_FFT_X_MAX; }
+static bool x_from(uint32_t log2n) { return log2n >= 11 && log2n <= 13; }
 #define SOTS_DISPATCH_X(log2n, CALL)      \
     switch (log2n) {                      \
     case 11: { CALL(11); break; }         \
@@ -2675,17 +2427,11 @@ static bool x_from(uint32_t log2n) { return SOTS_FFT_X != 0 && log2n >= 11 && lo
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus, OccCache *oc)
 {
-    int *occ = oc->fft, *occ_wg = oc->fft_wg;
+    int *occ = oc->fft;
     if (x_from(log2n)) {
         int *occ_x = oc->x_fft;
 #define CALL(L) k_fft_x<L, 0, false><<<SOTS_X_GRID((k_fft_x<L, 0, false>), L), x_waves<L>() * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
         SOTS_DISPATCH_X(log2n, CALL)
-#undef CALL
-        return hipGetLastError();
-    }
-    if (log2n >= wg_from()) {
-#define CALL(L) k_fft_wg<L, 0, false><<<resident_grid(k_fft_wg<L, 0, false>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
-        SOTS_DISPATCH_WG(log2n, CALL)
 #undef CALL
         return hipGetLastError();
     }
@@ -2698,17 +2444,11 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
-    int *occ = oc->fitness, *occ_wg = oc->fitness_wg;
+    int *occ = oc->fitness;
     if (x_from(log2n)) {
         int *occ_x = oc->x_fitness;
 #define CALL(L) k_fitness_x<L><<<SOTS_X_GRID(k_fitness_x<L>, L), x_waves<L>() * kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
         SOTS_DISPATCH_X(log2n, CALL)
-#undef CALL
-        return hipGetLastError();
-    }
-    if (log2n >= wg_from()) {
-#define CALL(L) k_fitness_wg<L><<<resident_grid(k_fitness_wg<L>, wg_threads<L>(), p, num_cus, &occ_wg[L]), wg_threads<L>(), 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
-        SOTS_DISPATCH_WG(log2n, CALL)
 #undef CALL
         return hipGetLastError();
     }
@@ -2722,7 +2462,7 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
                               float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
-    int *occ_w = oc->fused_win, *occ_n = oc->fused_raw, *occ_wgw = oc->fused_wg_win, *occ_wgn = oc->fused_wg_raw;
+    int *occ_w = oc->fused_win, *occ_n = oc->fused_raw;
     if (x_from(log2n)) {
         if (window) {
             int *occ_x = oc->x_fused_win;
@@ -2733,18 +2473,6 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
             int *occ_x = oc->x_fused_raw;
 #define CALL(L) k_fft_x<L, 1, false><<<SOTS_X_GRID((k_fft_x<L, 1, false>), L), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
             SOTS_DISPATCH_X(log2n, CALL)
-#undef CALL
-        }
-        return hipGetLastError();
-    }
-    if (log2n >= wg_from()) {
-        if (window) {
-#define CALL(L) k_fft_wg<L, 1, true><<<resident_grid(k_fft_wg<L, 1, true>, wg_threads<L>(), p, num_cus, &occ_wgw[L]), wg_threads<L>(), 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
-            SOTS_DISPATCH_WG(log2n, CALL)
-#undef CALL
-        } else {
-#define CALL(L) k_fft_wg<L, 1, false><<<resident_grid(k_fft_wg<L, 1, false>, wg_threads<L>(), p, num_cus, &occ_wgn[L]), wg_threads<L>(), 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
-            SOTS_DISPATCH_WG(log2n, CALL)
 #undef CALL
         }
         return hipGetLastError();

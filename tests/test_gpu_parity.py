@@ -561,7 +561,7 @@ def test_full_size_properties_config2(pkg, O):
 
 def test_full_size_properties_config3_shard(pkg, O):
     """BASELINE configs[3], the per-GPU shard of the 8-GPU run: P = 32768 (8192 + 24576), 4-op series,
-    N = 4096 - the regime where k_synth<3,2> is cut into two wavefronts and the transform is k_fft_wg<12>."""
+    N = 4096 - the regime where k_synth<3,2> is cut into two wavefronts and the transform is k_fft_x<12>."""
     full_size_properties(pkg, O, 8192, 24576, 3, 12)
 
 
