@@ -2181,7 +2181,9 @@ __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fft_x(const float 
             // pairs (this is the summation order, k_fitness_x repeats it), and a pair that is done is free - the NEXT
             // row's loads into those two registers go out at once, so by the end of the split most of the next row is on
             // its way without a second set of registers.
-            const float2 *__restrict__ in_next = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : row) * pitch);
+            // (a wavefront's last row has no successor: it re-reads row 0, which every wavefront of the launch then finds in
+            // L2 - loads under `if (more)` cost the compiler its register allocation)
+            const float2 *__restrict__ in_next = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : 0u) * pitch);
             static_for<0, E>([&](auto r_tag) {
                 constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
                 if constexpr (R2 >= RR) {
