@@ -1974,8 +1974,8 @@ template <int LOG2N> constexpr int x_points() { return (1 << LOG2N) / 2 / kWave;
 #ifndef SOTS_X_WAVES12
 #define SOTS_X_WAVES12 12
 #endif
-template <int LOG2N> constexpr int x_waves() { return LOG2N >= 13 ? 8 : LOG2N == 12 ? SOTS_X_WAVES12 : 12; } // wavefronts (independent rows) per workgroup
-template <int LOG2N> constexpr bool x_applies() { return LOG2N >= 11 && LOG2N <= 13; }
+template <int LOG2N> constexpr int x_waves() { return LOG2N >= 13 ? 8 : LOG2N == 12 ? SOTS_X_WAVES12 : LOG2N == 11 ? 12 : 16; } // wavefronts (independent rows) per workgroup
+template <int LOG2N> constexpr bool x_applies() { return LOG2N >= 10 && LOG2N <= 13; }
 
 // f(ic<I>{}) for I = FIRST .. LAST-1 with I a compile-time constant inside f (register arrays are indexed with it)
 template <int FIRST, int LAST, typename F>
@@ -2087,7 +2087,7 @@ __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fft_x(const float 
                                                                    const float2 *__restrict__ tw, const float *__restrict__ window,
                                                                    uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N>();
+    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N>();
     constexpr int S2 = E + 2, S1 = E + 4; // lane strides of the float2 / float tables (16-byte reads, spread over the banks)
     __shared__ __attribute__((aligned(16))) float2 tw2_s[kWave * S2], tws_s[kWave * S2], win_s[WIN ? kWave * S2 : 1];
     __shared__ __attribute__((aligned(16))) float tgt_s[MODE == 1 ? kWave * S1 : 4];
@@ -2246,7 +2246,7 @@ template <int LOG2N>
 __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fitness_x(const float *__restrict__ spectrum, const float *__restrict__ target,
                                                                        float *__restrict__ fitness, uint32_t p_len, float inv_n, float inv_wf)
 {
-    constexpr int N = 1 << LOG2N, E = x_points<LOG2N>(), EB = (E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N>();
+    constexpr int N = 1 << LOG2N, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N>();
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t pp = __brev(lane) >> 26;
     for (uint32_t row = blockIdx.x * W + wave; row < p_len; row += gridDim.x * W) {
@@ -2416,9 +2416,13 @@ static uint32_t resident_grid(K kernel, int threads, uint32_t items, uint32_t nu
     default: return hipErrorInvalidValue; \
     }
 
-static bool x_from(uint32_t log2n) { return log2n >= 11 && log2n <= 13; }
+#ifndef SOTS_X_MIN
+#define SOTS_X_MIN 11
+#endif
+static bool x_from(uint32_t log2n) { return log2n >= SOTS_X_MIN && log2n <= 13; }
 #define SOTS_DISPATCH_X(log2n, CALL)      \
     switch (log2n) {                      \
+    case 10: { CALL(10); break; }         \
     case 11: { CALL(11); break; }         \
     case 12: { CALL(12); break; }         \
     case 13: { CALL(13); break; }         \
