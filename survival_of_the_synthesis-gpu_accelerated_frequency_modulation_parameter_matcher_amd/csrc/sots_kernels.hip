@@ -1972,9 +1972,11 @@ constexpr int x_bitrev(int v, int bits)
 }
 template <int LOG2N> constexpr int x_points() { return (1 << LOG2N) / 2 / kWave; }
 #ifndef SOTS_X_WAVES12
-#define SOTS_X_WAVES12 12
+#define SOTS_X_WAVES12 16
 #endif
-template <int LOG2N> constexpr int x_waves() { return LOG2N >= 13 ? 8 : LOG2N == 12 ? SOTS_X_WAVES12 : LOG2N == 11 ? 12 : 16; } // wavefronts (independent rows) per workgroup
+// wavefronts (independent rows) per workgroup: what the registers allow (MODE 0, the spectrum writer of the stage-separated
+// path, needs a few more than the fused kernel)
+template <int LOG2N, int MODE = 1> constexpr int x_waves() { return LOG2N >= 13 ? 8 : LOG2N == 12 ? (MODE == 0 ? 12 : SOTS_X_WAVES12) : 16; }
 template <int LOG2N> constexpr bool x_applies() { return LOG2N >= 10 && LOG2N <= 13; }
 
 // f(ic<I>{}) for I = FIRST .. LAST-1 with I a compile-time constant inside f (register arrays are indexed with it)
@@ -2004,14 +2006,38 @@ __device__ __forceinline__ v2f_t x_row_load(const float2 *p)
 __device__ __forceinline__ v2f_t xv(float2 a) { return v2f_t{a.x, a.y}; }
 // a * w: (a.x, a.y) * w.x + (-a.y, a.x) * w.y - a packed multiply and a packed fma (operand selects and negations are
 // instruction modifiers)
+// The packed instructions select the low or high half of each source per result half (op_sel, op_sel_hi) and negate
+// per half (neg_lo, neg_hi); the compiler uses the selects but flips signs of single halves with v_xor and copies, so
+// the few shapes the transform needs are written out.
 __device__ __forceinline__ v2f_t xc_mul(v2f_t a, v2f_t w)
 {
-    const v2f_t t = a * __builtin_shufflevector(w, w, 0, 0);
-    const v2f_t ar = __builtin_shufflevector(a, a, 1, 0);
-    const v2f_t wy = __builtin_shufflevector(w, w, 1, 1);
-    return ar * v2f_t{-wy.x, wy.y} + t;
+    v2f_t t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                       // (a.x w.x, a.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t)); // (-a.y w.y, a.x w.y) + t
+    return r;
 }
 __device__ __forceinline__ v2f_t xc_mul_neg_i(v2f_t a) { return v2f_t{a.y, -a.x}; }
+// (-i a) * w = (a.y w.x + a.x w.y, a.y w.y - a.x w.x)
+__device__ __forceinline__ v2f_t xc_mul_negi_w(v2f_t a, v2f_t w)
+{
+    v2f_t t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));           // (a.y w.x, -a.x w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));        // (a.x w.y, a.y w.y) + t
+    return r;
+}
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ v2f_t xc_add_conj(v2f_t a, v2f_t b)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f_t xc_sub_conj(v2f_t a, v2f_t b)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // one radix-2 DIF stage of the E-point transform over the registers: pairs (a, a + H) inside groups of 2 H
 template <int H, int E, int N>
@@ -2045,7 +2071,7 @@ __device__ __forceinline__ void x_lane_stage(v2f_t (&x)[E], float sgn, v2f_t wl)
         const v2f_t p = v2f_t{lane_xor_f<H>(x[r].x), lane_xor_f<H>(x[r].y)};
         const v2f_t t = x[r] * v2f_t{sgn, sgn} + p;
         x[r] = H == 1 ? t : xc_mul(t, wl);
-        if (r % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0); // (four registers' partner fetches in flight at a time)
     }
 }
 
@@ -2077,17 +2103,17 @@ __device__ __forceinline__ void x_lane_stage_pairs(v2f_t (&x)[E], v2f_t w)
         v2f_t sum = x[r] + x[r + 1], dif = xc_mul(x[r] - x[r + 1], w);
         x_swap2<H>(sum, dif);
         x[r] = sum, x[r + 1] = dif;
-        if (r % 8 == 6) __builtin_amdgcn_sched_barrier(0);
+        if (r % 4 == 2) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 template <int LOG2N, int MODE, bool WIN>
-__global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
+__global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                                    const float *__restrict__ target, float *__restrict__ fitness,
                                                                    const float2 *__restrict__ tw, const float *__restrict__ window,
                                                                    uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N>();
+    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N, MODE>();
     constexpr int S2 = E + 2, S1 = E + 4; // lane strides of the float2 / float tables (16-byte reads, spread over the banks)
     __shared__ __attribute__((aligned(16))) float2 tw2_s[kWave * S2], tws_s[kWave * S2], win_s[WIN ? kWave * S2 : 1];
     __shared__ __attribute__((aligned(16))) float tgt_s[MODE == 1 ? kWave * S1 : 4];
@@ -2172,9 +2198,8 @@ __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fft_x(const float 
             const v2f_t zm = v2f_t{__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x[R2].x))),
                                    __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x[R2].y)))};
             const v2f_t w = xv(tws_s[lane * S2 + RR]);
-            const v2f_t b = v2f_t{zm.x, -zm.y};
-            const v2f_t ee = x[RR] + b, dd = x[RR] - b;
-            return ee + xc_mul(xc_mul_neg_i(dd), w); // 2 X[k] = (Z[k] + conj Z[M-k]) + W_N^k (-i) (Z[k] - conj Z[M-k])
+            const v2f_t ee = xc_add_conj(x[RR], zm), dd = xc_sub_conj(x[RR], zm);
+            return ee + xc_mul_negi_w(dd, w); // 2 X[k] = (Z[k] + conj Z[M-k]) + W_N^k (-i) (Z[k] - conj Z[M-k])
         };
         if constexpr (MODE == 1) {
             // Registers RR and R2 = bitrev(E - bitrev(RR)) need each other and nobody else: the bins are taken in such
@@ -2214,9 +2239,8 @@ __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fft_x(const float 
                                    __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x[R2].y)))};
             const v2f_t w = xv(tws_s[lane * S2 + RR]);
             // 2 X[k] = (Z[k] + conj Z[M-k]) + W_N^k (-i) (Z[k] - conj Z[M-k])
-            const v2f_t b = v2f_t{zm.x, -zm.y};
-            const v2f_t ee = x[RR] + b, dd = x[RR] - b;
-            const v2f_t x2 = ee + xc_mul(xc_mul_neg_i(dd), w);
+            const v2f_t ee = xc_add_conj(x[RR], zm), dd = xc_sub_conj(x[RR], zm);
+            const v2f_t x2 = ee + xc_mul_negi_w(dd, w);
             if constexpr (MODE == 0) {
                 if constexpr (Q % 2 == 0) out_even = x2 * v2f_t{0.5f, 0.5f};
                 else *reinterpret_cast<float4 *>(dst + Q - 1) = make_float4(out_even.x, out_even.y, 0.5f * x2.x, 0.5f * x2.y);
@@ -2428,7 +2452,7 @@ static bool x_from(uint32_t log2n) { return log2n >= SOTS_X_MIN && log2n <= 13; 
     case 13: { CALL(13); break; }         \
     default: return hipErrorInvalidValue; \
     }
-#define SOTS_X_GRID(K, L) resident_grid(K, x_waves<L>() * kWave, (p + x_waves<L>() - 1) / x_waves<L>(), num_cus, &occ_x[L])
+#define SOTS_X_GRID(K, L, MODE) resident_grid(K, x_waves<L, MODE>() * kWave, (p + x_waves<L, MODE>() - 1) / x_waves<L, MODE>(), num_cus, &occ_x[L])
 
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus, OccCache *oc)
@@ -2436,7 +2460,7 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
     int *occ = oc->fft;
     if (x_from(log2n)) {
         int *occ_x = oc->x_fft;
-#define CALL(L) k_fft_x<L, 0, false><<<SOTS_X_GRID((k_fft_x<L, 0, false>), L), x_waves<L>() * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
+#define CALL(L) k_fft_x<L, 0, false><<<SOTS_X_GRID((k_fft_x<L, 0, false>), L, 0), x_waves<L, 0>() * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
         SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         return hipGetLastError();
@@ -2453,7 +2477,7 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
     int *occ = oc->fitness;
     if (x_from(log2n)) {
         int *occ_x = oc->x_fitness;
-#define CALL(L) k_fitness_x<L><<<SOTS_X_GRID(k_fitness_x<L>, L), x_waves<L>() * kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
+#define CALL(L) k_fitness_x<L><<<SOTS_X_GRID(k_fitness_x<L>, L, 1), x_waves<L>() * kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
         SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         return hipGetLastError();
@@ -2472,12 +2496,12 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
     if (x_from(log2n)) {
         if (window) {
             int *occ_x = oc->x_fused_win;
-#define CALL(L) k_fft_x<L, 1, true><<<SOTS_X_GRID((k_fft_x<L, 1, true>), L), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+#define CALL(L) k_fft_x<L, 1, true><<<SOTS_X_GRID((k_fft_x<L, 1, true>), L, 1), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
             SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         } else {
             int *occ_x = oc->x_fused_raw;
-#define CALL(L) k_fft_x<L, 1, false><<<SOTS_X_GRID((k_fft_x<L, 1, false>), L), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
+#define CALL(L) k_fft_x<L, 1, false><<<SOTS_X_GRID((k_fft_x<L, 1, false>), L, 1), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
             SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         }
