@@ -452,6 +452,35 @@ def test_fused_generation_equals_staged(pkg, O, kind, log2n, parents, offspring)
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("log2n,parents,offspring", [(11, 2048 + 32, 6144 + 68), (12, 2048, 6144 + 100), (13, 1024 + 32, 3072 + 68)])
+def test_long_rows_several_per_wavefront(pkg, O, log2n, parents, offspring):
+    """k_fft_x (N >= 2048) with more rows than resident wavefronts (every wavefront loops, the next row's loads go
+    out while the current one is split) and a last workgroup that is not full: the fused generation equals the
+    stage-separated one bit for bit, and rows of the materialised spectrum - the first, a middle one, the last
+    ones - are the transform of the windowed audio."""
+    a, _ = make_pair(pkg, O, parents, offspring, 0, log2n, block=4)  # P = 4 mod 8: no whole number of 8- or 16-row workgroups
+    b, _ = make_pair(pkg, O, parents, offspring, 0, log2n, block=4)
+    assert a.P % 8 == 4
+    tgt, _ = target_audio(O, 0, a.N)
+    for es in (a, b):
+        es.set_target_audio(tgt)
+        es.init_population(0)
+    a.execute_generation()
+    b.execute_generations(1)
+    for x, y in zip(a.read_population(), b.read_population()):
+        assert np.array_equal(x, y)
+    # the stage-separated path left windowed audio and its spectrum behind
+    n, P = a.N, a.P
+    a.synthesise(); a.window(); a.fft()
+    audio, spec = a.read_audio(), a.read_spectrum()
+    ones = np.ones(n)
+    for i in (0, 1, P // 2 + 7, P - 17, P - 2, P - 1):
+        ref = O.rfft(audio[i], ones)
+        got = spec[i, : n // 2 + 1].astype(np.complex128)
+        assert np.abs(got - ref).max() <= FFT_TOL * max(np.abs(ref).max(), 1e-30), f"row {i}"
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (0, 9, 30, 35), (3, 12, 32, 96)])
 def test_audio_after_fused_loop_is_the_raw_synthesis(pkg, O, kind, log2n, parents, offspring):
     """The fused loop keeps the audio in its own (tiled) layout and leaves the window to the FFT
