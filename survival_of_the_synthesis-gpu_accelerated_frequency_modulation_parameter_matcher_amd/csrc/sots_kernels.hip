@@ -747,6 +747,45 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 }
 __device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); } // a * (-i)
 
+// ---- complex values as 2-vectors (register pairs): v_pk_add/mul/fma_f32 do a complex add, or half a complex
+// multiply, per instruction, and every wave64 vector instruction holds the SIMD for 4 cycles whatever it does
+__device__ __forceinline__ v2f_t xv(float2 a) { return v2f_t{a.x, a.y}; }
+// a * w: (a.x, a.y) * w.x + (-a.y, a.x) * w.y - a packed multiply and a packed fma (operand selects and negations are
+// instruction modifiers)
+// The packed instructions select the low or high half of each source per result half (op_sel, op_sel_hi) and negate
+// per half (neg_lo, neg_hi); the compiler uses the selects but flips signs of single halves with v_xor and copies, so
+// the few shapes the transform needs are written out.
+__device__ __forceinline__ v2f_t xc_mul(v2f_t a, v2f_t w)
+{
+    v2f_t t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                       // (a.x w.x, a.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t)); // (-a.y w.y, a.x w.y) + t
+    return r;
+}
+__device__ __forceinline__ v2f_t xc_mul_neg_i(v2f_t a) { return v2f_t{a.y, -a.x}; }
+// (-i a) * w = (a.y w.x + a.x w.y, a.y w.y - a.x w.x)
+__device__ __forceinline__ v2f_t xc_mul_negi_w(v2f_t a, v2f_t w)
+{
+    v2f_t t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));           // (a.y w.x, -a.x w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));        // (a.x w.y, a.y w.y) + t
+    return r;
+}
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ v2f_t xc_add_conj(v2f_t a, v2f_t b)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f_t xc_sub_conj(v2f_t a, v2f_t b)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+
 template <int R> struct Dft;
 template <> struct Dft<2> {
     static __device__ __forceinline__ void run(float2 *v)
@@ -950,20 +989,16 @@ __device__ __forceinline__ float2 split_partner(const float2 (&z)[M / kWave], in
     return lane == 0 ? mine : make_float2(px, py);
 }
 
-// HALVE = false leaves out the two 1/2 factors: the outputs are 2 X[k], 2 X[M-k] exactly (a factor of two is
-// exact in fp32), and the fitness path folds the 1/2 into its magnitude scale - four multiplies fewer per pair.
-template <bool HALVE = true>
-__device__ __forceinline__ void split_pair(float2 a, float2 bz, float2 w, float2 &xa, float2 &xb)
+// In packed form, without the two 1/2 factors: 2 X[k] and 2 conj X[M-k] (a factor of two is exact in fp32; the fitness
+// folds it into its magnitude scale and takes magnitudes, the spectrum writer halves and conjugates as it stores) - six
+// packed instructions for two bins
+__device__ __forceinline__ void split_pair_2x(float2 a, float2 bz, float2 w, v2f_t &xa2, v2f_t &xbc2)
 {
-    const float2 b = make_float2(bz.x, -bz.y);
-    const float h = HALVE ? 0.5f : 1.0f;
-    const float2 ee = HALVE ? make_float2(h * (a.x + b.x), h * (a.y + b.y)) : make_float2(a.x + b.x, a.y + b.y);
-    const float2 dd = HALVE ? make_float2(h * (a.x - b.x), h * (a.y - b.y)) : make_float2(a.x - b.x, a.y - b.y);
-    const float2 oo = make_float2(dd.y, -dd.x);
-    const float2 t = cmul(oo, w);
-    xa = cadd(ee, t);
-    const float2 d2 = csub(ee, t);
-    xb = make_float2(d2.x, -d2.y);
+    const v2f_t av = xv(a), bv = xv(bz);
+    const v2f_t ee = xc_add_conj(av, bv), dd = xc_sub_conj(av, bv);
+    const v2f_t t = xc_mul_negi_w(dd, xv(w));
+    xa2 = ee + t;
+    xbc2 = ee - t;
 }
 
 // (|X| * scale - target)^2 with scale = 1 / N / windowFactor, Evolutionary_Strategy.hpp:517-519 /
@@ -1080,10 +1115,10 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
 #pragma unroll
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
-                float2 xa, xb;
-                split_pair(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa, xb);
-                row[k] = xa;
-                row[M - k] = xb; // k = 0 lands on the Nyquist bin M
+                v2f_t xa2, xbc2;
+                split_pair_2x(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa2, xbc2);
+                row[k] = make_float2(0.5f * xa2.x, 0.5f * xa2.y);
+                row[M - k] = make_float2(0.5f * xbc2.x, -0.5f * xbc2.y); // k = 0 lands on the Nyquist bin M
             }
             if (lane == 0) row[M / 2] = x_half;
         } else {
@@ -1091,11 +1126,11 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
 #pragma unroll
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
-                float2 xa, xb;
-                split_pair<false>(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa, xb); // 2 X[k], 2 X[M-k]
-                if (k == 0) xb = make_float2(2.0f * x_half.x, 2.0f * x_half.y); // the fitness skips the Nyquist bin and needs bin M/2
-                acc += bin_error(xa, tgt_s[k], half_scale);
-                acc += bin_error(xb, tgt_s[k == 0 ? M / 2 : M - k], half_scale);
+                v2f_t xa2, xbc2;
+                split_pair_2x(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa2, xbc2); // 2 X[k], 2 conj X[M-k]
+                if (k == 0) xbc2 = v2f_t{2.0f * x_half.x, 2.0f * x_half.y}; // the fitness skips the Nyquist bin and needs bin M/2
+                acc += bin_error(make_float2(xa2.x, xa2.y), tgt_s[k], half_scale);
+                acc += bin_error(make_float2(xbc2.x, xbc2.y), tgt_s[k == 0 ? M / 2 : M - k], half_scale);
             }
             acc = wave_sum(acc);
             if (lane == 0) fitness[ind] = acc;
@@ -2003,42 +2038,6 @@ __device__ __forceinline__ v2f_t x_row_load(const float2 *p)
     return *reinterpret_cast<const v2f_t *>(p);
 #endif
 }
-__device__ __forceinline__ v2f_t xv(float2 a) { return v2f_t{a.x, a.y}; }
-// a * w: (a.x, a.y) * w.x + (-a.y, a.x) * w.y - a packed multiply and a packed fma (operand selects and negations are
-// instruction modifiers)
-// The packed instructions select the low or high half of each source per result half (op_sel, op_sel_hi) and negate
-// per half (neg_lo, neg_hi); the compiler uses the selects but flips signs of single halves with v_xor and copies, so
-// the few shapes the transform needs are written out.
-__device__ __forceinline__ v2f_t xc_mul(v2f_t a, v2f_t w)
-{
-    v2f_t t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                       // (a.x w.x, a.y w.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t)); // (-a.y w.y, a.x w.y) + t
-    return r;
-}
-__device__ __forceinline__ v2f_t xc_mul_neg_i(v2f_t a) { return v2f_t{a.y, -a.x}; }
-// (-i a) * w = (a.y w.x + a.x w.y, a.y w.y - a.x w.x)
-__device__ __forceinline__ v2f_t xc_mul_negi_w(v2f_t a, v2f_t w)
-{
-    v2f_t t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));           // (a.y w.x, -a.x w.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));        // (a.x w.y, a.y w.y) + t
-    return r;
-}
-// a + conj(b), a - conj(b)
-__device__ __forceinline__ v2f_t xc_add_conj(v2f_t a, v2f_t b)
-{
-    v2f_t r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f_t xc_sub_conj(v2f_t a, v2f_t b)
-{
-    v2f_t r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // one radix-2 DIF stage of the E-point transform over the registers: pairs (a, a + H) inside groups of 2 H
 template <int H, int E, int N>
 __device__ __forceinline__ void x_reg_stage(v2f_t (&x)[E], const float2 *__restrict__ tw)
