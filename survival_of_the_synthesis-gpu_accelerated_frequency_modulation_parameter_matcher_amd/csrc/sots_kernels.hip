@@ -356,7 +356,7 @@ template <int SPLIT, int SPLIT2, int OPS> struct CutPlan {
 };
 
 template <int KIND, int SPLIT, bool HELP = false, int SPLIT2 = 0>
-__global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(const float *__restrict__ values,
+__global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave) void k_synth(const float *__restrict__ values,
                                                                const float *__restrict__ wavetable,
                                                                float *__restrict__ audio, SynthParams sp,
                                                                uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
@@ -366,7 +366,7 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
     static_assert(U % 4 == 0 && 4 * kStageChunks % U == 0, "whole 16-byte chunks, whole blocks per flush");
     static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
     static_assert(SPLIT2 == 0 || (SPLIT > 0 && SPLIT2 > SPLIT && SPLIT2 < OPS), "the second cut lies behind the first");
-    static_assert(!HELP || (SPLIT == 0 && D == 4), "the helper wavefronts serve the uncut 4-gene voice");
+    static_assert(!HELP || (D == 4 && SPLIT <= 1 && SPLIT2 == 0), "the helper wavefronts serve the 4-gene voice, uncut or cut once");
     using Plan = CutPlan<SPLIT, SPLIT2, OPS>;
     constexpr int STAGES = Plan::STAGES;
     __shared__ float tab[kWavetableSize];
@@ -398,7 +398,7 @@ __global__ __launch_bounds__((HELP ? 16 : SPLIT2 ? 6 : 4) * kWave) void k_synth(
             }
         }
         __syncthreads();
-        if (wave_id >= pairs) {
+        if (wave_id >= STAGES * pairs) { // (a cut kernel keeps a wavefront per stage)
             __builtin_amdgcn_s_waitcnt(0); // this wavefront's pieces of the table have landed before it leaves
             return;
         }
@@ -2382,6 +2382,12 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     // variation folded in, 2-operator voice, full workgroups with one tile each: sixteen wavefronts make the individuals
     if (var.vin && kind == SOTS_SYNTH_2OP && !cut && (uint64_t)grid * waves * kWave * 2 >= p) { // one or two tiles per workgroup
         k_synth<SOTS_SYNTH_2OP, 0, true><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        return hipGetLastError();
+    }
+    // ... and the cut 2-operator kernel of a small population likewise: four times its wavefronts make the genes, then two per
+    // 64 individuals stay (one tile per workgroup there)
+    if (var.vin && kind == SOTS_SYNTH_2OP && cut && (uint64_t)grid * waves * kWave >= p) {
+        k_synth<SOTS_SYNTH_2OP, 1, true><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
         return hipGetLastError();
     }
 #define SOTS_SYNTH_CASE(K, S)                                                                            \
