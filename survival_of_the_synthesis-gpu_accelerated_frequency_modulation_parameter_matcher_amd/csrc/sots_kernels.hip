@@ -366,7 +366,8 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
     static_assert(U % 4 == 0 && 4 * kStageChunks % U == 0, "whole 16-byte chunks, whole blocks per flush");
     static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
     static_assert(SPLIT2 == 0 || (SPLIT > 0 && SPLIT2 > SPLIT && SPLIT2 < OPS), "the second cut lies behind the first");
-    static_assert(!HELP || (D == 4 && SPLIT <= 1 && SPLIT2 == 0), "the helper wavefronts serve the 4-gene voice, uncut or cut once");
+    static_assert(!HELP || SPLIT > 0 || D == 4, "uncut, the helper wavefronts serve the 4-gene voice (128 registers with 16 wavefronts)");
+    constexpr uint32_t HT = 4; // HELP: threads per individual while the genes are made (each takes genes t % 4, t % 4 + 4, ...)
     using Plan = CutPlan<SPLIT, SPLIT2, OPS>;
     constexpr int STAGES = Plan::STAGES;
     __shared__ float tab[kWavetableSize];
@@ -377,7 +378,7 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     // cut kernels: wavefronts [0, pairs) are the TAIL stage, [pairs, 2 pairs) the stage before it, ... of the same 64 individuals
-    const uint32_t pairs = HELP ? blockDim.x / (D * kWave) : blockDim.x / (STAGES * kWave);
+    const uint32_t pairs = HELP ? blockDim.x / (HT * kWave) : blockDim.x / (STAGES * kWave);
     // HELP: the tiles this workgroup will synthesise (1 or 2: blockIdx, blockIdx + gridDim)
     const uint32_t help_tiles = HELP ? (blockIdx.x * (pairs * kWave) + gridDim.x * (pairs * kWave) < p_len ? 2u : 1u) : 0u;
     if constexpr (HELP) {
@@ -385,16 +386,18 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
         // wavefronts that stay (the tile area is free until the first samples are parked; they take the second tile's
         // values into registers before they start on the first)
         float *__restrict__ made = reinterpret_cast<float *>(stage_all);
-        const uint32_t t = threadIdx.x, g1 = t % D;
+        const uint32_t t = threadIdx.x, li = t / HT; // the individual inside the tile
         for (uint32_t kt = 0; kt < help_tiles; ++kt) {
-            const uint32_t i1 = (blockIdx.x + kt * gridDim.x) * (pairs * kWave) + t / D;
+            const uint32_t i1 = (blockIdx.x + kt * gridDim.x) * (pairs * kWave) + li;
             if (i1 < p_len) {
-                const uint32_t src = recombine_source(i1, g1, var.pd);
-                float x = var.vin[src], st = var.sin[src];
-                mutate_gene(x, st, var.pd.gid_base + i1, g1, var.generation, var.pd, var.mc);
-                var.vout[(size_t)i1 * D + g1] = x;
-                var.sout[(size_t)i1 * D + g1] = st;
-                made[kt * (pairs * kWave * D) + t] = x;
+                for (uint32_t g1 = t % HT; g1 < (uint32_t)D; g1 += HT) {
+                    const uint32_t src = recombine_source(i1, g1, var.pd);
+                    float x = var.vin[src], st = var.sin[src];
+                    mutate_gene(x, st, var.pd.gid_base + i1, g1, var.generation, var.pd, var.mc);
+                    var.vout[(size_t)i1 * D + g1] = x;
+                    var.sout[(size_t)i1 * D + g1] = st;
+                    made[kt * (pairs * kWave * D) + li * D + g1] = x;
+                }
             }
         }
         __syncthreads();
@@ -2384,11 +2387,19 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         k_synth<SOTS_SYNTH_2OP, 0, true><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
         return hipGetLastError();
     }
-    // ... and the cut 2-operator kernel of a small population likewise: four times its wavefronts make the genes, then two per
-    // 64 individuals stay (one tile per workgroup there)
-    if (var.vin && kind == SOTS_SYNTH_2OP && cut && (uint64_t)grid * waves * kWave >= p) {
-        k_synth<SOTS_SYNTH_2OP, 1, true><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
-        return hipGetLastError();
+    // ... and the cut kernels of a small population likewise: four threads per individual make the genes (one, two or three
+    // each), then a wavefront per stage and 64 individuals stays (one tile per workgroup there)
+    if (var.vin && cut && (uint64_t)grid * waves * kWave >= p) {
+        const uint32_t ht = 4 * waves * kWave;
+        switch (kind) {
+        case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP, 1, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); return hipGetLastError();
+        case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES, 2, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); return hipGetLastError();
+        case SOTS_SYNTH_4OP_SERIES:
+            if (waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 2, true, 3><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+            else k_synth<SOTS_SYNTH_4OP_SERIES, 2, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+            return hipGetLastError();
+        default: break;
+        }
     }
 #define SOTS_SYNTH_CASE(K, S)                                                                            \
     case K:                                                                                              \
