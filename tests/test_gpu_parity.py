@@ -434,8 +434,10 @@ def test_lazy_tail_keeps_immigrants_and_full_sort_mode_matches(pkg, O):
 
 # the last case is large enough (>= 192 individuals per CU, 4 genes) for the fused loop to make its
 # individuals inside the synthesis kernel, with a partly filled last tile
+# (the last three: the cut kernels whose helper wavefronts make the genes - one group of 64 per CU, two groups, 3-op)
 @pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (3, 12, 32, 96), (2, 10, 32, 96),
-                                                          (0, 9, 16416, 49152)])
+                                                          (0, 9, 16416, 49152), (0, 10, 4096, 12288), (0, 10, 8192, 24576 - 32),
+                                                          (1, 10, 4096 + 32, 12288)])
 def test_fused_generation_equals_staged(pkg, O, kind, log2n, parents, offspring):
     a, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
     b, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
