@@ -286,6 +286,19 @@ int complete_tail(sots_ctx *ctx)
     return SOTS_OK;
 }
 
+// For every call that is about to WRITE population rows (a stage, write_population): the rows the selection left
+// out are produced first (SOTS_SORT_LAZY_TAIL), and whatever the mode the pending state ends here - the half it would
+// be completed from, or the rows it would fill, are about to change.  In SOTS_SORT_TOP_ONLY nothing is produced
+// (rows >= S stay unspecified); pure reads keep the state in that mode, so switching to SOTS_SORT_LAZY_TAIL while the
+// unsorted half is still intact completes it.
+int settle_tail(sots_ctx *ctx)
+{
+    if (int rc = complete_tail(ctx)) return rc;
+    ctx->tail_pending = false;
+    ctx->tail_first = 0;
+    return SOTS_OK;
+}
+
 int require_target(sots_ctx *ctx)
 {
     if (!ctx->target_set)
@@ -476,6 +489,9 @@ int sots_init_population(sots_ctx *ctx, uint32_t chunk_index)
     if (int rc = bind_device(ctx)) return rc;
     ctx->rot = 0; // initPopulationCL, ...OpenCL.hpp:371
     ctx->generation = 0;
+    // a tail the last run's selection left pending belongs to the OLD population: dropped, never completed into the new one
+    ctx->tail_pending = false;
+    ctx->tail_first = 0;
     {
         StageScope t(ctx, SOTS_STAGE_INIT);
         SOTS_HIP(ctx, launch_init_population(ctx->stream, ctx->val(0), ctx->stp(0), ctx->fit(0), ctx->pd, chunk_index));
@@ -508,7 +524,7 @@ int sots_write_population(sots_ctx *ctx, const float *values, size_t values_byte
                           size_t steps_bytes, const float *fitness, size_t fitness_bytes)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     return copy_population(ctx, ctx->rot, true, (void *)values, values_bytes, (void *)steps, steps_bytes,
                            (void *)fitness, fitness_bytes);
 }
@@ -568,7 +584,7 @@ int sots_read_synth(sots_ctx *ctx, float *audio, size_t audio_bytes, float *spec
 int sots_stage_recombine(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
     {
@@ -582,7 +598,7 @@ int sots_stage_recombine(sots_ctx *ctx)
 int sots_stage_mutate(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_MUTATE);
@@ -594,7 +610,7 @@ int sots_stage_mutate(sots_ctx *ctx)
 int sots_stage_synthesise(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_SYNTHESISE);
@@ -607,7 +623,7 @@ int sots_stage_synthesise(sots_ctx *ctx)
 int sots_stage_window(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_WINDOW);
@@ -619,7 +635,7 @@ int sots_stage_window(sots_ctx *ctx)
 int sots_stage_fft(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_FFT);
@@ -631,7 +647,7 @@ int sots_stage_fft(sots_ctx *ctx)
 int sots_stage_fitness(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = require_target(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     {
@@ -645,7 +661,7 @@ int sots_stage_fitness(sots_ctx *ctx)
 int sots_stage_sort(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u;
     {
@@ -659,7 +675,7 @@ int sots_stage_sort(sots_ctx *ctx)
 int sots_stage_select(sots_ctx *ctx)
 {
     SOTS_REQUIRE_CTX(ctx);
-    if (int rc = complete_tail(ctx)) return rc;
+    if (int rc = settle_tail(ctx)) return rc;
     if (int rc = bind_device(ctx)) return rc;
     const uint32_t src = ctx->rot, dst = ctx->rot ^ 1u, need = selected_rows(ctx);
     if (ctx->sort_mode == SOTS_SORT_FULL || !select_applies(ctx->P, need)) return sots_stage_sort(ctx);
@@ -682,7 +698,7 @@ int sots_stage_rotate(sots_ctx *ctx)
     if (ctx->tail_pending && ctx->tail_first == 0) { // sots_stage_select just ran: its rows are in the OTHER half
         ctx->tail_first = selected_rows(ctx);
     } else if (ctx->tail_pending) {
-        if (int rc = complete_tail(ctx)) return rc;
+        if (int rc = settle_tail(ctx)) return rc; // (the flip below would swap the halves under a pending state)
     }
     ctx->rot ^= 1u;
     ctx->generation += 1;
@@ -773,9 +789,10 @@ int sots_set_sort_mode(sots_ctx *ctx, uint32_t mode)
 {
     SOTS_REQUIRE_CTX(ctx);
     if (mode > SOTS_SORT_TOP_ONLY) return fail(ctx, SOTS_ERR_INVALID, "unknown sort mode %u", mode);
-    if (int rc = complete_tail(ctx)) return rc;
+    // the new mode decides what happens to a pending tail: leaving SOTS_SORT_TOP_ONLY completes it (the unsorted half
+    // is intact as long as the state is pending, settle_tail), entering it keeps the rows unspecified
     ctx->sort_mode = mode;
-    return SOTS_OK;
+    return complete_tail(ctx);
 }
 
 int sots_get_generation(const sots_ctx *ctx, uint32_t *generation)
@@ -844,8 +861,11 @@ int sots_pack_elites_device(sots_ctx *ctx, void *device_rows, uint32_t n_rows)
 {
     SOTS_REQUIRE_CTX(ctx);
     if (!device_rows || n_rows > ctx->P) return fail(ctx, SOTS_ERR_INVALID, "pack_elites: bad rows/n_rows %u", n_rows);
-    if (ctx->tail_pending && n_rows > ctx->tail_first)
+    if (ctx->tail_pending && n_rows > ctx->tail_first) {
+        if (ctx->sort_mode == SOTS_SORT_TOP_ONLY)
+            return fail(ctx, SOTS_ERR_STATE, "pack_elites: %u rows asked for, SOTS_SORT_TOP_ONLY placed %u", n_rows, ctx->tail_first);
         if (int rc = complete_tail(ctx)) return rc;
+    }
     if (int rc = bind_device(ctx)) return rc;
     SOTS_HIP(ctx, launch_pack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
                                    (float *)device_rows, 0, n_rows, ctx->D));

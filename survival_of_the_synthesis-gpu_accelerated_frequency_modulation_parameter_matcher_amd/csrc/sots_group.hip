@@ -5,11 +5,16 @@
 // type.HIP.{numDevices,numElites,migrationInterval} drive; bench.py keeps one PROCESS per GPU over
 // torch.distributed, which is the same exchange seen from the other side.
 //
-//   * every island has its own host thread while generations run: a generation is 4-6 launches, and
-//     eight islands launched from one thread would be host-bound (about 4 us per launch against
-//     ~150 us of GPU work per generation);
+//   * every island has its own PERSISTENT host thread (island 0: the caller's): a generation is 4-6 launches, and
+//     eight islands launched from one thread would be host-bound (about 4 us per launch against ~150 us of GPU
+//     work per generation).  The threads are made once per group, spin for a job for a few hundred microseconds
+//     and then sleep on a condition variable, so sots_group_execute_generations(1) in a loop (the C++ class's
+//     executeGeneration) does not pay a thread creation per call;
 //   * exchange, every `interval` generations: pack (island stream) -> all-gather -> inject the other
-//     islands' rows into the tail of the breeding rows (sots_inject_gathered_device);
+//     islands' rows into the tail of the breeding rows (sots_inject_gathered_device).  Buffers alternate with
+//     the exchange count, so the only cross-island ordering the HOST has to provide is "every `packed` event of this
+//     exchange is recorded before anybody waits for it": one host barrier per exchange with the copy backend, none
+//     with RCCL (every thread issues its own device's ncclAllGather; the devices meet inside the collective);
 //   * schedules as in island.py: same generation, or overlapped (the all-gather started after
 //     generation g runs on a side stream underneath generation g+1 and is injected after g+1's sort);
 //   * backends: RCCL (distinct devices; librccl is opened with dlopen when the first multi-device
@@ -20,6 +25,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -40,8 +46,6 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -76,32 +80,74 @@ Rccl *load_rccl(std::string &err)
     SOTS_SYM(CommInitAll, "ncclCommInitAll")
     SOTS_SYM(CommDestroy, "ncclCommDestroy")
     SOTS_SYM(AllGather, "ncclAllGather")
-    SOTS_SYM(GroupStart, "ncclGroupStart")
-    SOTS_SYM(GroupEnd, "ncclGroupEnd")
     SOTS_SYM(GetErrorString, "ncclGetErrorString")
 #undef SOTS_SYM
     return &lib;
 }
 
-// reusable barrier for the island threads (C++17: no std::barrier)
-class HostBarrier
+// Reusable barrier for the island threads.  They meet once per exchange, a few microseconds apart (each has just
+// enqueued the same few launches), so they spin; a thread that has spun for long (an island fewer CPUs than threads)
+// yields its time slice.
+class SpinBarrier
 {
-    std::mutex mu_;
-    std::condition_variable cv_;
-    uint32_t waiting_ = 0, phase_ = 0, n_;
+    std::atomic<uint32_t> waiting_{0}, phase_{0};
+    uint32_t n_;
 
 public:
-    explicit HostBarrier(uint32_t n) : n_(n) {}
+    explicit SpinBarrier(uint32_t n) : n_(n) {}
     void arrive_and_wait()
     {
-        std::unique_lock<std::mutex> lock(mu_);
-        const uint32_t phase = phase_;
-        if (++waiting_ == n_) {
-            waiting_ = 0;
-            ++phase_;
-            cv_.notify_all();
-        } else {
-            cv_.wait(lock, [&] { return phase_ != phase; });
+        const uint32_t phase = phase_.load(std::memory_order_acquire);
+        if (waiting_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+            waiting_.store(0, std::memory_order_relaxed);
+            phase_.store(phase + 1, std::memory_order_release);
+            return;
+        }
+        for (uint32_t spins = 0; phase_.load(std::memory_order_acquire) == phase; ++spins) {
+            if (spins < 4096) __builtin_ia32_pause();
+            else std::this_thread::yield();
+        }
+    }
+};
+
+// What the caller's thread tells the workers.  Workers spin on `seq` for a while after a job (the next call usually
+// follows at once) and then sleep on the condition variable; `seq` only changes under the mutex, so no wake-up is lost.
+struct JobGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> seq{0};
+    std::atomic<uint32_t> done{0};
+    uint32_t n = 0;        // generations of the current job
+    int pending_in = -1;   // the group's `pending` when the job was posted
+    bool quit = false;
+
+    void post(uint32_t n_generations, int pending, bool quit_now)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            n = n_generations;
+            pending_in = pending;
+            quit = quit_now;
+            done.store(0, std::memory_order_relaxed);
+            seq.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_all();
+    }
+    // returns once seq != seen
+    void wait_job(uint64_t seen)
+    {
+        for (uint32_t spins = 0; spins < 200000; ++spins) { // a few hundred microseconds
+            if (seq.load(std::memory_order_acquire) != seen) return;
+            __builtin_ia32_pause();
+        }
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return seq.load(std::memory_order_acquire) != seen; });
+    }
+    void wait_done(uint32_t workers)
+    {
+        for (uint32_t spins = 0; done.load(std::memory_order_acquire) != workers; ++spins) {
+            if (spins < 4096) __builtin_ia32_pause();
+            else std::this_thread::yield();
         }
     }
 };
@@ -115,7 +161,6 @@ struct Island {
     float *gathered[2] = {nullptr, nullptr}; // all islands' elites in island order
     hipEvent_t packed[2] = {nullptr, nullptr};   // mine[b] is complete
     hipEvent_t arrived[2] = {nullptr, nullptr};  // gathered[b] is complete
-    hipEvent_t consumed[2] = {nullptr, nullptr}; // every reader of mine[b] has issued its copy (local backend)
     ncclComm_t comm = nullptr;
 };
 
@@ -128,9 +173,16 @@ struct sots_group {
     bool use_rccl = false;
     Rccl *rccl = nullptr;
     uint32_t generation = 0; // generations run since the last init_population
+    uint32_t exchanges = 0;  // exchanges done since then: exchange x uses buffers x & 1
     int pending = -1;        // buffer index of the all-gather in flight (overlapped schedule), -1 = none
     std::mutex err_mu;       // island threads may fail at the same time
     std::string err;
+    // persistent island threads (islands 1..n-1; island 0 runs on the caller's thread)
+    std::vector<std::thread> workers;
+    JobGate gate;
+    SpinBarrier *barrier = nullptr;
+    std::vector<int> rcs;    // per island, result of the current job
+    int pending_out = -1;    // island 0's view of `pending` at the end of the job
 };
 
 namespace {
@@ -154,6 +206,13 @@ int gfail(sots_group *g, int code, const char *fmt, ...)
 void destroy_group(sots_group *g)
 {
     if (!g) return;
+    if (!g->workers.empty()) {
+        g->gate.post(0, -1, true);
+        for (auto &t : g->workers) t.join();
+        g->workers.clear();
+    }
+    delete g->barrier;
+    g->barrier = nullptr;
     for (Island &is : g->islands) {
         if (!is.ctx && !is.stream) continue; // never got as far as its device
         (void)hipSetDevice(is.device);
@@ -166,7 +225,6 @@ void destroy_group(sots_group *g)
             if (is.gathered[b]) (void)hipFree(is.gathered[b]);
             if (is.packed[b]) (void)hipEventDestroy(is.packed[b]);
             if (is.arrived[b]) (void)hipEventDestroy(is.arrived[b]);
-            if (is.consumed[b]) (void)hipEventDestroy(is.consumed[b]);
         }
         if (is.side) (void)hipStreamDestroy(is.side);
         if (is.stream) (void)hipStreamDestroy(is.stream);
@@ -186,84 +244,120 @@ int exchange_pack(sots_group *g, uint32_t i, int b)
 {
     Island &is = g->islands[i];
     GROUP_HIP(g, hipSetDevice(is.device));
-    // a reader of the previous use of this buffer may still be copying from it (local backend)
-    GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.consumed[b], 0));
+    // The previous use of this buffer pair (two exchanges ago) must be over on the device before mine[b] is overwritten:
+    // with RCCL this island's own collective read it (arrived[b] of this island); with the copy backend every island
+    // copied from it (everybody's arrived[b]).  Those events were recorded before the barrier of the exchange in
+    // between, so this thread sees them.  Waiting here gates nothing but the pack: the events are one exchange old.
+    if (g->use_rccl) {
+        GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.arrived[b], 0));
+    } else {
+        for (Island &reader : g->islands) GROUP_HIP(g, hipStreamWaitEvent(is.stream, reader.arrived[b], 0));
+    }
     if (int rc = sots_pack_elites_device(is.ctx, is.mine[b], g->elites)) return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
     GROUP_HIP(g, hipEventRecord(is.packed[b], is.stream));
     return SOTS_OK;
 }
 
-// Step 2 with RCCL, all islands at once from one thread (a group call, as RCCL wants for one process
-// driving several devices).  `on_side`: the collective runs on the side streams.
-int exchange_gather_rccl(sots_group *g, int b, bool on_side)
+// Step 2, island i's share: gathered[b] of island i <- every island's mine[b].  `on_side`: on the side stream.
+// RCCL: this device's rank of the all-gather, called from this island's thread (one thread per device: no group
+// call; the ranks meet on the devices).  Copy backend: one copy per island, each behind the owner's `packed` event -
+// which the owner's thread recorded before the host barrier the caller has just passed.
+int exchange_gather(sots_group *g, uint32_t i, int b, bool on_side)
 {
-    const size_t count = (size_t)g->elites * g->width;
-    for (Island &is : g->islands)
-        if (on_side) {
-            GROUP_HIP(g, hipSetDevice(is.device));
-            GROUP_HIP(g, hipStreamWaitEvent(is.side, is.packed[b], 0));
-        }
-    ncclResult_t r = g->rccl->GroupStart();
-    if (r != ncclSuccess) return gfail(g, SOTS_ERR_HIP, "ncclGroupStart: %s", g->rccl->GetErrorString(r));
-    for (Island &is : g->islands) {
-        r = g->rccl->AllGather(is.mine[b], is.gathered[b], count, ncclFloat, is.comm, on_side ? is.side : is.stream);
-        if (r != ncclSuccess) {
-            (void)g->rccl->GroupEnd();
-            return gfail(g, SOTS_ERR_HIP, "ncclAllGather: %s", g->rccl->GetErrorString(r));
-        }
-    }
-    r = g->rccl->GroupEnd();
-    if (r != ncclSuccess) return gfail(g, SOTS_ERR_HIP, "ncclGroupEnd: %s", g->rccl->GetErrorString(r));
-    for (Island &is : g->islands) {
-        GROUP_HIP(g, hipSetDevice(is.device));
-        GROUP_HIP(g, hipEventRecord(is.arrived[b], on_side ? is.side : is.stream));
-    }
-    return SOTS_OK;
-}
-
-// Step 2 without RCCL (islands sharing a device): island i copies every island's block into its own
-// gathered[b], each copy behind the owner's `packed` event.
-int exchange_gather_copies(sots_group *g, int b, bool on_side)
-{
-    const size_t bytes = (size_t)g->elites * g->width * sizeof(float);
-    const uint32_t n = (uint32_t)g->islands.size();
-    for (uint32_t i = 0; i < n; ++i) {
-        Island &is = g->islands[i];
-        GROUP_HIP(g, hipSetDevice(is.device));
-        hipStream_t st = on_side ? is.side : is.stream;
+    Island &is = g->islands[i];
+    GROUP_HIP(g, hipSetDevice(is.device));
+    hipStream_t st = on_side ? is.side : is.stream;
+    const size_t count = (size_t)g->elites * g->width, bytes = count * sizeof(float);
+    if (g->use_rccl) {
+        if (on_side) GROUP_HIP(g, hipStreamWaitEvent(st, is.packed[b], 0));
+        const ncclResult_t r = g->rccl->AllGather(is.mine[b], is.gathered[b], count, ncclFloat, is.comm, st);
+        if (r != ncclSuccess) return gfail(g, SOTS_ERR_HIP, "island %u: ncclAllGather: %s", i, g->rccl->GetErrorString(r));
+    } else {
+        const uint32_t n = (uint32_t)g->islands.size();
         for (uint32_t j = 0; j < n; ++j) {
             Island &from = g->islands[j];
-            GROUP_HIP(g, hipStreamWaitEvent(st, from.packed[b], 0));
+            if (j != i || on_side) GROUP_HIP(g, hipStreamWaitEvent(st, from.packed[b], 0));
             char *dst = reinterpret_cast<char *>(is.gathered[b]) + (size_t)j * bytes;
             if (from.device == is.device) GROUP_HIP(g, hipMemcpyAsync(dst, from.mine[b], bytes, hipMemcpyDeviceToDevice, st));
             else GROUP_HIP(g, hipMemcpyPeerAsync(dst, is.device, from.mine[b], from.device, bytes, st));
         }
-        GROUP_HIP(g, hipEventRecord(is.arrived[b], st));
     }
-    // mine[b] of island j may be packed again once every reader has finished: its stream then waits for all of them
-    for (uint32_t j = 0; j < n; ++j) {
-        Island &from = g->islands[j];
-        GROUP_HIP(g, hipSetDevice(from.device));
-        for (uint32_t i = 0; i < n; ++i) GROUP_HIP(g, hipStreamWaitEvent(from.stream, g->islands[i].arrived[b], 0));
-        GROUP_HIP(g, hipEventRecord(from.consumed[b], from.stream));
-    }
+    GROUP_HIP(g, hipEventRecord(is.arrived[b], st));
     return SOTS_OK;
-}
-
-int exchange_gather(sots_group *g, int b, bool on_side)
-{
-    return g->use_rccl ? exchange_gather_rccl(g, b, on_side) : exchange_gather_copies(g, b, on_side);
 }
 
 // Step 3, island i: the other islands' rows into the tail of its breeding rows.
-int exchange_inject(sots_group *g, uint32_t i, int b)
+int exchange_inject(sots_group *g, uint32_t i, int b, bool wait_event)
 {
     Island &is = g->islands[i];
     GROUP_HIP(g, hipSetDevice(is.device));
-    GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.arrived[b], 0));
+    if (wait_event) GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.arrived[b], 0)); // (the same stream otherwise)
     if (int rc = sots_inject_gathered_device(is.ctx, is.gathered[b], (uint32_t)g->islands.size(), i, g->elites))
         return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
     return SOTS_OK;
+}
+
+// n generations of island i with the exchanges that fall due.  Every island's thread runs this with the same
+// arguments and therefore takes the same branches; between two exchanges a thread only talks to its own device.
+// Nothing here waits for the GPU.  A failed island keeps taking part in barriers and collectives (the others must not hang).
+int run_island(sots_group *g, uint32_t i, uint32_t n, int pending, int *pending_out)
+{
+    const uint32_t islands = (uint32_t)g->islands.size();
+    const bool exchange = g->elites > 0 && (islands > 1 || (g->flags & SOTS_GROUP_FORCE_RCCL));
+    const bool overlap = (g->flags & SOTS_GROUP_OVERLAP) != 0;
+    int rc = SOTS_OK;
+    if (!exchange) {
+        rc = sots_execute_generations(g->islands[i].ctx, n);
+        if (rc) rc = gfail(g, rc, "island %u: %s", i, sots_last_error(g->islands[i].ctx));
+        *pending_out = -1;
+        return rc;
+    }
+    const bool host_barrier = !g->use_rccl && islands > 1;
+    auto keep = [&](int r) { if (!rc && r) rc = r; };
+    uint32_t x = g->exchanges; // exchanges done so far (the same value in every thread)
+    // generations up to the next exchange go out in one call
+    uint32_t k = 0;
+    while (k < n) {
+        uint32_t run = g->interval - (g->generation + k) % g->interval; // generations until one is due
+        if (run > n - k) run = n - k;
+        if (!rc) {
+            const int r = sots_execute_generations(g->islands[i].ctx, run);
+            if (r) keep(gfail(g, r, "island %u: %s", i, sots_last_error(g->islands[i].ctx)));
+        }
+        k += run;
+        if ((g->generation + k) % g->interval != 0) break; // (the job ended before the next exchange)
+        const int b = (int)(x & 1u);
+        ++x;
+        if (!overlap) {
+            keep(exchange_pack(g, i, b));
+            if (host_barrier) g->barrier->arrive_and_wait(); // every island has recorded `packed`
+            keep(exchange_gather(g, i, b, false));
+            if (!rc) keep(exchange_inject(g, i, b, false));
+        } else {
+            // rows gathered at the previous exchange arrive now; this exchange's go out underneath the next generations
+            if (!rc && pending >= 0) keep(exchange_inject(g, i, pending, true));
+            keep(exchange_pack(g, i, b));
+            if (host_barrier) g->barrier->arrive_and_wait();
+            keep(exchange_gather(g, i, b, true));
+            pending = b;
+        }
+    }
+    *pending_out = overlap ? pending : -1;
+    return rc;
+}
+
+void worker_main(sots_group *g, uint32_t i)
+{
+    uint64_t seen = 0;
+    (void)hipSetDevice(g->islands[i].device);
+    for (;;) {
+        g->gate.wait_job(seen);
+        seen = g->gate.seq.load(std::memory_order_acquire);
+        if (g->gate.quit) return;
+        int unused = -1;
+        g->rcs[i] = run_island(g, i, g->gate.n, g->gate.pending_in, &unused);
+        g->gate.done.fetch_add(1, std::memory_order_release);
+    }
 }
 
 } // namespace
@@ -325,17 +419,19 @@ int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uin
         CREATE_HIP(hipStreamCreateWithFlags(&is.stream, hipStreamNonBlocking));
         CREATE_HIP(hipStreamCreateWithFlags(&is.side, hipStreamNonBlocking));
         if (int rc = sots_set_stream(is.ctx, is.stream)) CREATE_FAIL(rc, "island %u: %s", i, sots_last_error(is.ctx));
+        // immigrants overwrite the tail of the rows recombination reads: whole parent blocks (sots_inject_gathered_device)
         const uint64_t immigrants = (uint64_t)(num_devices - 1) * g->elites;
-        if (g->elites > p64 || immigrants > island_cfg->num_parents)
-            CREATE_FAIL(SOTS_ERR_INVALID, "%u elites from each of %u other islands do not fit %u parents", g->elites, num_devices - 1,
-                        island_cfg->num_parents);
+        const uint32_t block = island_cfg->workgroup_size ? island_cfg->workgroup_size : 1u;
+        const uint32_t npb = island_cfg->num_parents / block ? island_cfg->num_parents / block : 1u;
+        if (g->elites > p64 || immigrants > (uint64_t)npb * block)
+            CREATE_FAIL(SOTS_ERR_INVALID, "%u elites from each of %u other islands do not fit the %u parent rows recombination reads",
+                        g->elites, num_devices - 1, npb * block);
         const size_t mine_bytes = (size_t)(g->elites ? g->elites : 1) * g->width * sizeof(float);
         for (int b = 0; b < 2; ++b) {
             CREATE_HIP(hipMalloc((void **)&is.mine[b], mine_bytes));
             CREATE_HIP(hipMalloc((void **)&is.gathered[b], mine_bytes * num_devices));
             CREATE_HIP(hipEventCreateWithFlags(&is.packed[b], hipEventDisableTiming));
             CREATE_HIP(hipEventCreateWithFlags(&is.arrived[b], hipEventDisableTiming));
-            CREATE_HIP(hipEventCreateWithFlags(&is.consumed[b], hipEventDisableTiming));
         }
     }
     if (g->use_rccl) {
@@ -350,6 +446,9 @@ int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uin
     }
 #undef CREATE_HIP
 #undef CREATE_FAIL
+    g->rcs.assign(num_devices, SOTS_OK);
+    g->barrier = new SpinBarrier(num_devices);
+    for (uint32_t i = 1; i < num_devices; ++i) g->workers.emplace_back(worker_main, g, i);
     *out = g;
     return SOTS_OK;
 }
@@ -398,6 +497,7 @@ int sots_group_init_population(sots_group *g, uint32_t chunk_index)
     if (int rc = sots_group_synchronize(g)) return rc; // an all-gather in flight is dropped with the old population
     g->pending = -1;
     g->generation = 0;
+    g->exchanges = 0;
     for (size_t i = 0; i < g->islands.size(); ++i)
         if (int rc = sots_init_population(g->islands[i].ctx, chunk_index)) return gfail(g, rc, "island %zu: %s", i, sots_last_error(g->islands[i].ctx));
     return SOTS_OK;
@@ -406,67 +506,19 @@ int sots_group_init_population(sots_group *g, uint32_t chunk_index)
 int sots_group_execute_generations(sots_group *g, uint32_t n)
 {
     if (!g) return gfail(nullptr, SOTS_ERR_INVALID, "null group");
+    if (n == 0) return SOTS_OK;
     const uint32_t islands = (uint32_t)g->islands.size();
+    // the job goes to the persistent island threads; island 0 runs here
+    if (islands > 1) g->gate.post(n, g->pending, false);
+    int pending_out = -1;
+    g->rcs[0] = run_island(g, 0, n, g->pending, &pending_out);
+    if (islands > 1) g->gate.wait_done(islands - 1);
     const bool exchange = g->elites > 0 && (islands > 1 || (g->flags & SOTS_GROUP_FORCE_RCCL));
-    const bool overlap = (g->flags & SOTS_GROUP_OVERLAP) != 0;
-    if (!exchange) { // nothing to exchange: every island just runs (still one thread each)
-        std::vector<std::thread> threads;
-        std::vector<int> rcs(islands, SOTS_OK);
-        for (uint32_t i = 1; i < islands; ++i)
-            threads.emplace_back([&, i] { rcs[i] = sots_execute_generations(g->islands[i].ctx, n); });
-        rcs[0] = sots_execute_generations(g->islands[0].ctx, n);
-        for (auto &t : threads) t.join();
-        for (uint32_t i = 0; i < islands; ++i)
-            if (rcs[i]) return gfail(g, rcs[i], "island %u: %s", i, sots_last_error(g->islands[i].ctx));
-        g->generation += n;
-        return SOTS_OK;
-    }
-
-    // One thread per island.  Between two exchanges a thread only talks to its own device; at an exchange
-    // the threads meet at a host barrier, thread 0 issues the all-gather for everybody (the collective is
-    // ordered on the device by events / by RCCL itself), they meet again and go on.  Nothing here waits
-    // for the GPU.
-    HostBarrier barrier(islands);
-    std::vector<int> rcs(islands, SOTS_OK);
-    int gather_rc = SOTS_OK;
-    int pending = g->pending;
-    const uint32_t gen0 = g->generation;
-    auto worker = [&](uint32_t i) {
-        int my_pending = pending; // every thread tracks the same value
-        int rc = SOTS_OK;
-        for (uint32_t k = 0; k < n; ++k) {
-            if (!rc) rc = sots_execute_generations(g->islands[i].ctx, 1); // a failed island keeps meeting the others at the barriers
-            const bool due = (gen0 + k + 1) % g->interval == 0;
-            if (!due) continue;
-            if (!overlap) {
-                if (!rc) rc = exchange_pack(g, i, 0);
-                barrier.arrive_and_wait(); // every island has recorded `packed`
-                if (i == 0) gather_rc = exchange_gather(g, 0, false);
-                barrier.arrive_and_wait(); // `arrived` is recorded for everybody
-                if (!rc && !gather_rc) rc = exchange_inject(g, i, 0);
-            } else {
-                // rows gathered at the previous exchange arrive now; this exchange's go out underneath the next generations
-                if (!rc && my_pending >= 0) rc = exchange_inject(g, i, my_pending);
-                const int b = my_pending == 0 ? 1 : 0;
-                if (!rc) rc = exchange_pack(g, i, b);
-                barrier.arrive_and_wait();
-                if (i == 0) gather_rc = exchange_gather(g, b, true);
-                barrier.arrive_and_wait();
-                my_pending = b;
-            }
-        }
-        rcs[i] = rc;
-        if (i == 0) pending = my_pending;
-    };
-    std::vector<std::thread> threads;
-    for (uint32_t i = 1; i < islands; ++i) threads.emplace_back(worker, i);
-    worker(0);
-    for (auto &t : threads) t.join();
-    g->pending = overlap ? pending : -1;
+    if (exchange) g->exchanges += (g->generation + n) / g->interval - g->generation / g->interval;
+    g->pending = pending_out;
     g->generation += n;
-    if (gather_rc) return gather_rc; // g->err set by the gather
     for (uint32_t i = 0; i < islands; ++i)
-        if (rcs[i]) return rcs[i];
+        if (g->rcs[i]) return g->rcs[i]; // g->err holds the text of one of the failures
     return SOTS_OK;
 }
 

@@ -1509,8 +1509,9 @@ constexpr uint32_t kSelTile = 1024, kSelSamples = 4, kSelQuantum = kSelTile / kS
 constexpr uint32_t kSelThreads = 1024, kSelLanesPerKey = 8, kSelKeysPerRound = kSelThreads / kSelLanesPerKey;
 constexpr uint32_t kSelCap = 35328;                 // staged keys per pass: 138 KiB of LDS
 constexpr uint32_t kSelSkew = 4;                    // consecutive tiles start 4 more words (16 B) off the 1 KiB grid, see below
-// 16..128 tiles: from 256 tiles on the k-th-sample search (quadratic in the tile count) and the four or more LDS
-// passes cost more than the two-level full sort (170 against 88 us at P = 262144)
+// the rank kernel handles 16..128 tiles of either size: 1024-key tiles up to P = 65536, four-by-four merged tiles of 4096
+// keys up to P = 262144 (select_applies); with 256 unmerged tiles the k-th-sample search (quadratic in the tile count)
+// and four or more LDS passes cost more than the two-level full sort (170 against 88 us at P = 262144)
 constexpr uint32_t kSelMinTiles = 16, kSelMaxTiles = 128, kSelMaxOwn = 512; // kSelMaxTiles: tiles the rank kernel handles (of either size)
 
 // order-preserving bits of a fitness: every number (at most 0xFF800000, +inf) below NaN (0xFFFFFFFD), NaN

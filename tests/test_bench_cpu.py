@@ -79,3 +79,145 @@ def test_config_presets_name_the_baseline_workloads():
         for cfg in (2, 3, 4):
             pa, off, *_ = bench.resolve_workload(cfg, g)
             assert pa % 32 == 0 and off % 32 == 0
+
+
+def test_plain_command_with_several_gpus_starts_the_ranks_before_touching_torch_or_hip(tmp_path):
+    """`python bench.py --gpus N` (no rank environment): the N ranks are started as CHILD processes by
+    torch.distributed.run before this process has imported torch or opened libsots_hip (never
+    re-exec or fork a process that has touched the GPU)."""
+    import json
+    import subprocess
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import json, os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "os.environ.pop('WORLD_SIZE', None); os.environ.pop('RANK', None)\n"
+        "import bench\n"
+        "seen = {}\n"
+        "def fake_run(cmd, env=None, **kw):\n"
+        "    seen['cmd'] = cmd\n"
+        "    seen['torch_imported'] = 'torch' in sys.modules\n"
+        "    seen['hip_library_open'] = any('libsots_hip' in l for l in open('/proc/self/maps'))\n"
+        "    seen['ipc'] = (env or {}).get('HSA_ENABLE_IPC_MODE_LEGACY')\n"
+        "    class R: returncode = 7\n"
+        "    return R()\n"
+        "bench.subprocess.run = fake_run\n"
+        "try:\n"
+        "    bench.main(['--gpus', '4', '--steps', '3', '--warmup', '1', '--config', '3'])\n"
+        "except SystemExit as e:\n"
+        "    seen['exit'] = e.code\n"
+        "print(json.dumps(seen))\n")
+    out = subprocess.run([sys.executable, str(probe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    seen = json.loads(out.stdout.strip().splitlines()[-1])
+    assert seen["torch_imported"] is False and seen["hip_library_open"] is False
+    assert seen["exit"] == 7  # the ranks' return code is ours
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "3"][-7:]
+    assert seen["ipc"] == "0"
+
+
+def test_launcher_is_not_used_by_ranks_the_group_host_or_one_gpu():
+    import argparse
+    bench = importlib.import_module("bench")
+    ns = lambda **kw: argparse.Namespace(**kw)
+    old = os.environ.pop("WORLD_SIZE", None)
+    try:
+        assert bench.self_launch_command(ns(gpus=1, host="process"), []) is None
+        assert bench.self_launch_command(ns(gpus=8, host="group"), []) is None
+        assert bench.self_launch_command(ns(gpus=8, host="process"), ["--gpus", "8"]) is not None
+        os.environ["WORLD_SIZE"] = "8"
+        assert bench.self_launch_command(ns(gpus=8, host="process"), ["--gpus", "8"]) is None
+    finally:
+        os.environ.pop("WORLD_SIZE", None)
+        if old is not None:
+            os.environ["WORLD_SIZE"] = old
+
+
+class _FakeClock:
+    D = 4
+
+    def __init__(self, log):
+        self.log = log
+
+    def timing_enable(self, on=True):
+        self.log.append(("timing", bool(on)))
+
+    def timing_reset(self):
+        self.log.append(("reset",))
+
+    def stage_time_ms(self, stage):
+        return 1.0, 8
+
+
+class _FakeHost:
+    name = "fake"
+
+    def __init__(self):
+        self.log = []
+        self.clock = _FakeClock(self.log)
+
+    def init_population(self):
+        self.log.append(("init",))
+
+    def set_sort_mode(self, mode):
+        self.log.append(("sort_mode", mode))
+
+    def run(self, n):
+        self.log.append(("run", n))
+
+    def fence(self):
+        self.log.append(("fence",))
+
+    def all_ranks_agree(self, flag):
+        return True
+
+    def finish(self):
+        self.log.append(("finish",))
+
+    def best_fitness(self):
+        return 0.5
+
+
+def test_timed_region_runs_with_per_kernel_timing_off():
+    """the metric is the un-instrumented loop.  The K timed steps sit between two fences with nothing
+    else in between, timing was switched off before them, and the event pass comes afterwards."""
+    import argparse
+    bench = importlib.import_module("bench")
+    host = _FakeHost()
+    args = argparse.Namespace(settle_ms=0.0, warmup=5, steps=20, sustain=0.0, event_steps=8, full_sort_steps=20, full_sort=False)
+    out = bench.measure(host, args, (("synthesise", 10, 4096),), 1)
+    log = host.log
+    i = log.index(("run", 20))
+    assert log[i - 1] == ("fence",) and log[i + 1] == ("fence",)          # exactly K steps between two fences
+    assert ("timing", True) not in log[:i + 2]                             # nothing switched timing on before or inside
+    assert ("timing", False) in log[:i]
+    j = log.index(("timing", True))
+    assert j > i and log[j + 1] == ("run", 8)                              # the disclosed event pass, afterwards
+    # the reference's full sort beside the headline, also timed with timing off
+    k = log.index(("sort_mode", 1))
+    r = log.index(("run", 20), k)
+    assert log[r - 1] == ("fence",) and log[r + 1] == ("fence",) and ("timing", True) not in log[k:r + 2]
+    assert out["kernels"]["synthesise"]["launches"] == 8 and out["full_sort"]["steps"] == 20
+
+
+def test_pmc_traffic_is_dropped_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    import json
+    bench = importlib.import_module("bench")
+    (tmp_path / "profiles").mkdir()
+    now = bench.kernels_source_sha16()
+    assert now and len(now) == 16
+    table = {"workloads": {"fresh": {"kernels_sha16": now, "synthesise": 123}, "old": {"kernels_sha16": "0" * 16, "synthesise": 456},
+                           "untagged": {"synthesise": 789}}}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(table))
+    sha = bench.kernels_source_sha16
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernels_source_sha16", sha.__wrapped__ if hasattr(sha, "__wrapped__") else (lambda: now))
+    entry, src = bench.load_pmc_traffic("fresh")
+    assert entry["synthesise"] == 123 and "stale" not in src
+    for key in ("old", "untagged"):
+        entry, src = bench.load_pmc_traffic(key)
+        assert entry == {} and src.startswith("stale")
+    assert bench.load_pmc_traffic("missing") == ({}, None)

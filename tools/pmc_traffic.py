@@ -1,6 +1,7 @@
 """profiles/pmc_traffic.json (HBM bytes per launch of each fused-loop kernel, keyed by workload) from a
 pmc_summary.json of tools/pmc_collect.sh:
     python tools/pmc_traffic.py <pmc_summary.json> <workload key, e.g. P65536_N1024_2op> [round tag]"""
+import hashlib
 import json
 import os
 import sys
@@ -20,7 +21,12 @@ def pick(prefix):
     return max(ks, key=lambda k: d[k].get("dispatches_seen", 0))
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "survival_of_the_synthesis-gpu_accelerated_frequency_modulation_parameter_matcher_amd"
+# bench.py reports these figures only while the kernel source is the one they were collected on
+sha16 = hashlib.sha256(open(os.path.join(ROOT, PKG, "csrc", "sots_kernels.hip"), "rb").read()).hexdigest()[:16]
 entry = {"_round": tag,
+         "kernels_sha16": sha16,
          "synthesise": round(nbytes(pick("k_synth"))),
          "window+FFT+fitness": round(nbytes(pick("k_fft"))),
          "recombine+mutate": round(nbytes("k_recombine_mutate")) if "k_recombine_mutate" in d else None,
