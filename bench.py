@@ -209,7 +209,12 @@ def self_launch(cmd):
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
-    return subprocess.run(cmd, env=env).returncode
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        # rank 0's JSON line is the ONE line of this command; anything else the ranks print (gloo's connection
+        # banner, for one) goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    return proc.returncode
 
 
 # ---- the two hosts of the island model -------------------------------------------------------------------
@@ -235,14 +240,12 @@ class ProcessHost:
         self.es.set_sort_mode(mode)
 
     def init_population(self):
-        self.island.finish()
-        self.island.pending = None
+        self.island.restart()
         self.es.init_population(0)
 
     def run(self, n):
         for _ in range(n):
-            self.es.execute_generations(1)
-            self.island.migrate_device(self.es)
+            self.island.generation(self.es)  # the generation + its elite exchange (pack and inject inside the sort kernel)
 
     def fence(self):
         self.torch.cuda.synchronize(self.device)
@@ -472,6 +475,8 @@ def main(argv=None):
     if cmd is not None:
         raise SystemExit(self_launch(cmd))
 
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"  # the image sets VERSION: RCCL then prints a banner on STDOUT, beside the one JSON line
     import torch
 
     rank = int(os.environ.get("RANK", "0"))

@@ -197,6 +197,20 @@ int sots_inject_immigrants_device(sots_ctx *ctx, const void *device_rows, uint32
  * island's rows except this rank's own block (one launch, no intermediate copy) */
 int sots_inject_gathered_device(sots_ctx *ctx, const void *gathered_rows, uint32_t world, uint32_t rank,
                                 uint32_t elites);
+/* The same exchange WITHOUT its two launches: the sortPopulation of the LAST generation of the next
+ * sots_execute_generations call also (a) takes the immigrant rows straight from gathered_rows (as
+ * sots_inject_gathered_device would after that sort) and (b) writes the best n_elite_rows rows of the result, immigrants
+ * included where the ranges overlap, to elite_rows (as sots_pack_elites_device would after the inject).  Either
+ * pointer may be NULL; both are device pointers that must be ready when that sort runs on the context's stream and
+ * stay valid until it has.  Used once, then forgotten; sots_init_population forgets it too.  Where sortPopulation
+ * places only the rows recombination reads (enum sots_sort_mode), n_elite_rows may not exceed them.
+ * host_gate_event (optional, a hipEvent_t): for gathered_rows filled by a collective on ANOTHER stream.  The host waits
+ * for the event (hipEventSynchronize) right before it enqueues that sort - the generation's variation, synthesis and
+ * spectral kernels are on the stream by then, so the device stays busy - instead of the stream waiting for it: on this
+ * runtime a cross-stream hipStreamWaitEvent costs the waiting stream ~18 us per generation even for an event that
+ * completed long ago.  With NULL the caller orders the rows on the context's stream itself. */
+int sots_fuse_exchange_next_sort(sots_ctx *ctx, void *elite_rows, uint32_t n_elite_rows, const void *gathered_rows,
+                                 uint32_t world, uint32_t rank, uint32_t elites, void *host_gate_event);
 int sots_pack_elites_host(sots_ctx *ctx, float *rows, uint32_t n_rows);
 int sots_inject_immigrants_host(sots_ctx *ctx, const float *rows, uint32_t n_rows);
 
@@ -213,8 +227,14 @@ int sots_inject_immigrants_host(sots_ctx *ctx, const float *rows, uint32_t n_row
 enum sots_group_flags {
     SOTS_GROUP_OVERLAP = 1,    /* the all-gather started after generation g runs on a side stream underneath
                                 * generation g+1 and is injected after g+1's sort (rows arrive one exchange later) */
-    SOTS_GROUP_FORCE_RCCL = 2  /* use RCCL even for a single island (a one-rank communicator; exercises the
+    SOTS_GROUP_FORCE_RCCL = 2, /* use RCCL even for a single island (a one-rank communicator; exercises the
                                 * collective path on a one-GPU machine) */
+    SOTS_GROUP_EVENT_WAITS = 8,/* overlapped schedule: the island's STREAM waits for the side stream's events instead of its host
+                                * thread (sots_fuse_exchange_next_sort, host_gate_event): same results, ~18 us per
+                                * generation slower on this runtime; for tests and timing comparisons */
+    SOTS_GROUP_UNFUSED = 4     /* pack and inject as launches of their own (sots_pack_elites_device,
+                                * sots_inject_gathered_device) instead of inside the sort kernels
+                                * (sots_fuse_exchange_next_sort): same results, for tests and timing comparisons */
 };
 typedef struct sots_group sots_group;
 int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uint32_t num_devices,

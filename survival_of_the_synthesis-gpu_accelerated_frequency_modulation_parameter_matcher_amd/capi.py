@@ -44,13 +44,14 @@ EXPORTS = [
     "sots_execute_generation", "sots_execute_generations", "sots_get_generation",
     "sots_set_generation", "sots_timing_enable", "sots_timing_reset", "sots_stage_time_ms",
     "sots_stage_launch_times_ms",
-    "sots_pack_elites_device", "sots_inject_immigrants_device", "sots_inject_gathered_device", "sots_pack_elites_host",
+    "sots_pack_elites_device", "sots_inject_immigrants_device", "sots_inject_gathered_device", "sots_fuse_exchange_next_sort",
+    "sots_pack_elites_host",
     "sots_inject_immigrants_host", "sots_get_info",
     "sots_group_create", "sots_group_destroy", "sots_group_last_error", "sots_group_size", "sots_group_uses_rccl",
     "sots_group_island", "sots_group_set_target_audio", "sots_group_set_target_spectrum", "sots_group_init_population",
     "sots_group_execute_generations", "sots_group_synchronize", "sots_group_best",
 ]
-GROUP_OVERLAP, GROUP_FORCE_RCCL = 1, 2
+GROUP_OVERLAP, GROUP_FORCE_RCCL, GROUP_UNFUSED, GROUP_EVENT_WAITS = 1, 2, 4, 8
 MAX_GROUP_DEVICES = 16
 
 
@@ -123,6 +124,7 @@ def load():
     L.sots_pack_elites_device.argtypes = [vp, vp, u32]
     L.sots_inject_immigrants_device.argtypes = [vp, vp, u32]
     L.sots_inject_gathered_device.argtypes = [vp, vp, u32, u32, u32]
+    L.sots_fuse_exchange_next_sort.argtypes = [vp, vp, u32, vp, u32, u32, u32, vp]
     L.sots_pack_elites_host.argtypes = [vp, vp, u32]
     L.sots_inject_immigrants_host.argtypes = [vp, vp, u32]
     L.sots_get_info.argtypes = [vp, C.POINTER(Info)]
@@ -377,6 +379,20 @@ class HipES:
     def inject_gathered_device(self, dev_ptr, world, rank, elites):
         self._check(self.L.sots_inject_gathered_device(self._h, C.c_void_p(dev_ptr), world, rank, elites))
 
+    def sort_places(self, n_rows):
+        """True when every generation's sortPopulation places at least the first n_rows rows (the selection places
+        rows 0..S-1 only, S = the whole parent blocks and never fewer than the parents; enum sots_sort_mode)."""
+        block = max(1, self.cfg.workgroup_size)
+        breeding = max(1, self.cfg.num_parents // block) * block
+        return n_rows <= max(breeding, self.cfg.num_parents)
+
+    def fuse_exchange_next_sort(self, elite_ptr, n_elite_rows, gathered_ptr, world, rank, elites, host_gate_event=None):
+        """pack + inject folded into the sort of the last generation of the next execute_generations call; the host
+        waits for host_gate_event (a raw hipEvent_t) right before it enqueues that sort"""
+        self._check(self.L.sots_fuse_exchange_next_sort(self._h, C.c_void_p(elite_ptr) if elite_ptr else None, n_elite_rows,
+                                                        C.c_void_p(gathered_ptr) if gathered_ptr else None, world, rank, elites,
+                                                        C.c_void_p(host_gate_event) if host_gate_event else None))
+
     def pack_elites(self, n_rows):
         rows = np.empty((n_rows, 2 * self.D + 1), np.float32)
         self._check(self.L.sots_pack_elites_host(self._h, _ptr(rows), n_rows))
@@ -392,12 +408,12 @@ class HipGroup:
 
     def __init__(self, devices, num_elites, num_parents, num_offspring, synth_kind=SYNTH_2OP, audio_log2=10,
                  param_min=None, param_max=None, seed=0x5EED0001, workgroup_size=32, gid_base=0,
-                 migration_interval=1, overlap=False, force_rccl=False):
+                 migration_interval=1, overlap=False, force_rccl=False, unfused=False, event_waits=False):
         self.L = load()
         self.cfg = make_config(num_parents, num_offspring, synth_kind, audio_log2, param_min, param_max, seed, workgroup_size,
                                0, gid_base)
         devs = (C.c_int32 * len(devices))(*devices)
-        flags = (GROUP_OVERLAP if overlap else 0) | (GROUP_FORCE_RCCL if force_rccl else 0)
+        flags = (GROUP_OVERLAP if overlap else 0) | (GROUP_FORCE_RCCL if force_rccl else 0) | (GROUP_UNFUSED if unfused else 0) | (GROUP_EVENT_WAITS if event_waits else 0)
         h = C.c_void_p()
         rc = self.L.sots_group_create(C.byref(self.cfg), devs, len(devices), num_elites, migration_interval, flags, C.byref(h))
         if rc != 0:

@@ -61,6 +61,10 @@ struct sots_ctx {
     uint32_t sort_mode = SOTS_SORT_LAZY_TAIL;
     bool tail_pending = false;
     uint32_t tail_first = 0;
+    // island exchange folded into the sort of the last generation of the next sots_execute_generations call
+    SortExchange next_exchange{};
+    bool next_exchange_set = false;
+    hipEvent_t next_exchange_gate = nullptr; // the HOST waits for it right before that sort is enqueued
     // experiment switches; fixed in the shipped library, settable from the environment only in a
     // -DSOTS_EXPERIMENT build (tools/exp_*.sh)
     bool allow_cut = true;
@@ -492,6 +496,7 @@ int sots_init_population(sots_ctx *ctx, uint32_t chunk_index)
     // a tail the last run's selection left pending belongs to the OLD population: dropped, never completed into the new one
     ctx->tail_pending = false;
     ctx->tail_first = 0;
+    ctx->next_exchange_set = false;
     {
         StageScope t(ctx, SOTS_STAGE_INIT);
         SOTS_HIP(ctx, launch_init_population(ctx->stream, ctx->val(0), ctx->stp(0), ctx->fit(0), ctx->pd, chunk_index));
@@ -729,6 +734,13 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         return fail(ctx, SOTS_ERR_STATE, "sots_stage_select must be followed by sots_stage_rotate");
     const uint32_t need = selected_rows(ctx);
     const bool select = ctx->sort_mode != SOTS_SORT_FULL && select_applies(ctx->P, need);
+    // an exchange folded into the last generation's sort (sots_fuse_exchange_next_sort) is used once
+    const SortExchange exchange = ctx->next_exchange;
+    const bool with_exchange = ctx->next_exchange_set && n > 0;
+    hipEvent_t gate = with_exchange ? ctx->next_exchange_gate : nullptr;
+    if (n > 0) ctx->next_exchange_set = false, ctx->next_exchange_gate = nullptr;
+    if (with_exchange && select && exchange.sink && exchange.sink_rows > need)
+        return fail(ctx, SOTS_ERR_INVALID, "fused exchange: %u elite rows asked for, sortPopulation places %u per generation here", exchange.sink_rows, need);
     for (uint32_t g = 0; g < n; ++g) {
         // the variation below overwrites the unsorted half a pending tail would be completed from; nobody has
         // asked for those rows, so they are dropped
@@ -767,13 +779,20 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         dst = ctx->rot ^ 1u;
         {
             StageScope t(ctx, SOTS_STAGE_SORT, true);
+            const SortExchange *ex = with_exchange && g + 1 == n ? &exchange : nullptr;
+            // The rows this sort takes were gathered on ANOTHER stream.  The host waits for that collective here, with this
+            // generation's variation, synthesis and spectral kernels already on the stream (the GPU stays busy, and the
+            // collective - started a generation ago - is normally long done), instead of making the stream wait: on this
+            // runtime a cross-stream event wait costs the waiting stream ~18 us even when the event is complete
+            // (tools/ubench/cross_stream.hip).  A kernel launched after the host has seen the event sees the rows.
+            if (ex && gate) SOTS_HIP(ctx, hipEventSynchronize(gate));
             if (select) {
                 // the rows recombination reads, in order; the rest of the order is produced on demand
                 SOTS_HIP(ctx, launch_select(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst),
-                                            ctx->stp(dst), ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D, need, ctx->num_cus));
+                                            ctx->stp(dst), ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D, need, ctx->num_cus, ex));
             } else {
                 SOTS_HIP(ctx, launch_sort(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst), ctx->stp(dst),
-                                          ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D));
+                                          ctx->fit(dst), ctx->keys, ctx->sort_scratch, ctx->P, ctx->D, 0, ex));
             }
         }
         ctx->rot = dst;
@@ -896,6 +915,39 @@ int sots_inject_gathered_device(sots_ctx *ctx, const void *gathered_rows, uint32
     SOTS_HIP(ctx, launch_unpack_rows(ctx->stream, ctx->val(ctx->rot), ctx->stp(ctx->rot), ctx->fit(ctx->rot),
                                      (const float *)gathered_rows, breeding_rows(ctx) - (uint32_t)n_rows, (uint32_t)n_rows,
                                      ctx->D, rank * elites, elites));
+    return SOTS_OK;
+}
+
+int sots_fuse_exchange_next_sort(sots_ctx *ctx, void *elite_rows, uint32_t n_elite_rows, const void *gathered_rows,
+                                 uint32_t world, uint32_t rank, uint32_t elites, void *host_gate_event)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    ctx->next_exchange_set = false;
+    ctx->next_exchange_gate = nullptr;
+    SortExchange ex{};
+    if (elite_rows) {
+        if (n_elite_rows == 0 || n_elite_rows > ctx->P) return fail(ctx, SOTS_ERR_INVALID, "fused exchange: bad elite row count %u", n_elite_rows);
+        ex.sink = (float *)elite_rows;
+        ex.sink_rows = n_elite_rows;
+    }
+    if (gathered_rows) {
+        if (world == 0 || rank >= world) return fail(ctx, SOTS_ERR_INVALID, "fused exchange: bad arguments (world %u, rank %u)", world, rank);
+        const uint64_t n_rows = (uint64_t)(world - 1) * elites;
+        if (n_rows > breeding_rows(ctx))
+            return fail(ctx, SOTS_ERR_INVALID, "fused exchange: %llu immigrant rows do not fit the %u parent rows recombination reads",
+                        (unsigned long long)n_rows, breeding_rows(ctx));
+        if (n_rows) {
+            ex.imm = (const float *)gathered_rows;
+            ex.imm_first = breeding_rows(ctx) - (uint32_t)n_rows;
+            ex.imm_rows = (uint32_t)n_rows;
+            ex.skip_first = rank * elites;
+            ex.skip_count = elites;
+        }
+    }
+    if (!ex.sink && !ex.imm) return SOTS_OK; // nothing to fold in
+    ctx->next_exchange = ex;
+    ctx->next_exchange_set = true;
+    ctx->next_exchange_gate = (hipEvent_t)host_gate_event;
     return SOTS_OK;
 }
 

@@ -171,6 +171,11 @@ struct sots_group {
     sots_config island_cfg{};
     uint32_t elites = 0, interval = 1, flags = 0, width = 0;
     bool use_rccl = false;
+    bool fused = true; // pack and inject ride in the sort kernels (sots_fuse_exchange_next_sort) instead of two launches each
+    // overlapped schedule: an island's HOST THREAD waits for the side stream's gather (sots_fuse_exchange_next_sort,
+    // host_gate_event) instead of its compute stream: a cross-stream hipStreamWaitEvent costs the waiting stream ~18 us
+    // per generation on this runtime, even for an event that completed long ago (tools/ubench/cross_stream.hip)
+    bool host_gated = false;
     Rccl *rccl = nullptr;
     uint32_t generation = 0; // generations run since the last init_population
     uint32_t exchanges = 0;  // exchanges done since then: exchange x uses buffers x & 1
@@ -239,21 +244,57 @@ void destroy_group(sots_group *g)
         if (e_ != hipSuccess) return gfail(g, SOTS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-// Step 1 of an exchange, island i: its best rows into mine[b] on its own stream.
-int exchange_pack(sots_group *g, uint32_t i, int b)
+// Before mine[b] is written again: the previous use of this buffer pair (two exchanges ago) must be over on the
+// device.  With RCCL this island's own collective read it (arrived[b] of this island); with the copy backend every
+// island copied from it (everybody's arrived[b]).  Those events were recorded before the barrier of the exchange in
+// between, so this thread sees them; they are an exchange old, so the wait gates nothing.
+int exchange_reuse_wait(sots_group *g, uint32_t i, int b)
 {
     Island &is = g->islands[i];
     GROUP_HIP(g, hipSetDevice(is.device));
-    // The previous use of this buffer pair (two exchanges ago) must be over on the device before mine[b] is overwritten:
-    // with RCCL this island's own collective read it (arrived[b] of this island); with the copy backend every island
-    // copied from it (everybody's arrived[b]).  Those events were recorded before the barrier of the exchange in
-    // between, so this thread sees them.  Waiting here gates nothing but the pack: the events are one exchange old.
     if (g->use_rccl) {
         GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.arrived[b], 0));
     } else {
         for (Island &reader : g->islands) GROUP_HIP(g, hipStreamWaitEvent(is.stream, reader.arrived[b], 0));
     }
+    return SOTS_OK;
+}
+
+// Step 1 of an exchange, island i: its best rows into mine[b] on its own stream.  Fused form, BEFORE the generations
+// are enqueued: the last generation's sort writes them (and, in the overlapped schedule, takes the rows gathered at
+// the previous exchange straight from gathered[pending]: step 3 without its launch).
+int exchange_prepare_fused(sots_group *g, uint32_t i, int b, int pending)
+{
+    Island &is = g->islands[i];
+    // Who may still read mine[b] (filled at exchange x - 2)?  With host gating nobody: this thread has waited for its own
+    // gather of exchange x - 2 at the gate of exchange x - 1, and (copy backend) every other thread for theirs before
+    // the host barrier of exchange x - 1, which this thread has passed.  Otherwise the stream waits for the events.
+    hipEvent_t gate = nullptr;
+    if (g->host_gated) {
+        if (pending >= 0) gate = is.arrived[pending];
+    } else {
+        if (int rc = exchange_reuse_wait(g, i, b)) return rc;
+        if (pending >= 0) GROUP_HIP(g, hipStreamWaitEvent(is.stream, is.arrived[pending], 0));
+    }
+    if (int rc = sots_fuse_exchange_next_sort(is.ctx, is.mine[b], g->elites, pending >= 0 ? is.gathered[pending] : nullptr,
+                                              (uint32_t)g->islands.size(), i, g->elites, gate))
+        return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
+    return SOTS_OK;
+}
+
+// ... and the launch it replaces
+int exchange_pack(sots_group *g, uint32_t i, int b)
+{
+    Island &is = g->islands[i];
+    if (int rc = exchange_reuse_wait(g, i, b)) return rc;
     if (int rc = sots_pack_elites_device(is.ctx, is.mine[b], g->elites)) return gfail(g, rc, "island %u: %s", i, sots_last_error(is.ctx));
+    return SOTS_OK;
+}
+
+int exchange_packed(sots_group *g, uint32_t i, int b)
+{
+    Island &is = g->islands[i];
+    GROUP_HIP(g, hipSetDevice(is.device));
     GROUP_HIP(g, hipEventRecord(is.packed[b], is.stream));
     return SOTS_OK;
 }
@@ -320,27 +361,26 @@ int run_island(sots_group *g, uint32_t i, uint32_t n, int pending, int *pending_
     while (k < n) {
         uint32_t run = g->interval - (g->generation + k) % g->interval; // generations until one is due
         if (run > n - k) run = n - k;
+        const bool due = (g->generation + k + run) % g->interval == 0;
+        const int b = (int)(x & 1u);
+        if (due && g->fused) keep(exchange_prepare_fused(g, i, b, overlap ? pending : -1));
         if (!rc) {
             const int r = sots_execute_generations(g->islands[i].ctx, run);
             if (r) keep(gfail(g, r, "island %u: %s", i, sots_last_error(g->islands[i].ctx)));
         }
         k += run;
-        if ((g->generation + k) % g->interval != 0) break; // (the job ended before the next exchange)
-        const int b = (int)(x & 1u);
+        if (!due) break; // (the job ended before the next exchange)
         ++x;
-        if (!overlap) {
+        if (!g->fused) {
+            // rows gathered at the previous exchange arrive now (overlapped schedule), then this exchange's are packed
+            if (overlap && !rc && pending >= 0) keep(exchange_inject(g, i, pending, true));
             keep(exchange_pack(g, i, b));
-            if (host_barrier) g->barrier->arrive_and_wait(); // every island has recorded `packed`
-            keep(exchange_gather(g, i, b, false));
-            if (!rc) keep(exchange_inject(g, i, b, false));
-        } else {
-            // rows gathered at the previous exchange arrive now; this exchange's go out underneath the next generations
-            if (!rc && pending >= 0) keep(exchange_inject(g, i, pending, true));
-            keep(exchange_pack(g, i, b));
-            if (host_barrier) g->barrier->arrive_and_wait();
-            keep(exchange_gather(g, i, b, true));
-            pending = b;
         }
+        keep(exchange_packed(g, i, b));
+        if (host_barrier) g->barrier->arrive_and_wait(); // every island has recorded `packed`
+        keep(exchange_gather(g, i, b, overlap));          // overlapped: on the side stream, underneath the next generations
+        if (overlap) pending = b;
+        else if (!rc) keep(exchange_inject(g, i, b, false));
     }
     *pending_out = overlap ? pending : -1;
     return rc;
@@ -408,6 +448,7 @@ int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uin
         if (e_ != hipSuccess) CREATE_FAIL(SOTS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+    const unsigned ev_flags = hipEventDisableTiming; // (hipEventReleaseToDevice changes nothing measurable: profiles/r03_experiments.md)
     for (uint32_t i = 0; i < num_devices; ++i) {
         Island &is = g->islands[i];
         is.device = devices[i];
@@ -430,8 +471,8 @@ int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uin
         for (int b = 0; b < 2; ++b) {
             CREATE_HIP(hipMalloc((void **)&is.mine[b], mine_bytes));
             CREATE_HIP(hipMalloc((void **)&is.gathered[b], mine_bytes * num_devices));
-            CREATE_HIP(hipEventCreateWithFlags(&is.packed[b], hipEventDisableTiming));
-            CREATE_HIP(hipEventCreateWithFlags(&is.arrived[b], hipEventDisableTiming));
+            CREATE_HIP(hipEventCreateWithFlags(&is.packed[b], ev_flags));
+            CREATE_HIP(hipEventCreateWithFlags(&is.arrived[b], ev_flags));
         }
     }
     if (g->use_rccl) {
@@ -446,6 +487,15 @@ int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uin
     }
 #undef CREATE_HIP
 #undef CREATE_FAIL
+    {
+        // sortPopulation places rows 0..S-1 per generation where the selection applies (enum sots_sort_mode); elites beyond
+        // them need the completed order, i.e. the separate pack launch
+        const uint32_t block = island_cfg->workgroup_size ? island_cfg->workgroup_size : 1u;
+        const uint32_t npb = island_cfg->num_parents / block ? island_cfg->num_parents / block : 1u;
+        const uint32_t placed = npb * block > island_cfg->num_parents ? npb * block : island_cfg->num_parents;
+        g->fused = g->elites <= placed && !(flags & SOTS_GROUP_UNFUSED);
+        g->host_gated = g->fused && (flags & SOTS_GROUP_OVERLAP) && !(flags & SOTS_GROUP_EVENT_WAITS);
+    }
     g->rcs.assign(num_devices, SOTS_OK);
     g->barrier = new SpinBarrier(num_devices);
     for (uint32_t i = 1; i < num_devices; ++i) g->workers.emplace_back(worker_main, g, i);

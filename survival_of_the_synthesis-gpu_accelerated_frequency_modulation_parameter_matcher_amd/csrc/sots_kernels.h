@@ -86,6 +86,20 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
                               float inv_n, float inv_wf, uint32_t num_cus, OccCache *occ);
 
+// Island exchange folded into sortPopulation (one generation of the fused loop, set through
+// sots_fuse_exchange_next_sort): the kernel that moves the sorted rows also
+//   * takes destination rows [imm_first, imm_first + imm_rows) from `imm` (rows [fitness, values.., steps..] of an
+//     all-gathered buffer, source rows [skip_first, skip_first + skip_count) - the island's own block - passed
+//     over) instead of from the local population: sots_inject_gathered_device without its launch;
+//   * copies the best `sink_rows` rows - immigrants included where the ranges overlap - to `sink` in the same row
+//     format: sots_pack_elites_device without its launch.
+// Either pointer may be null.
+struct SortExchange {
+    float *sink;
+    const float *imm;
+    uint32_t sink_rows, imm_first, imm_rows, skip_first, skip_count;
+};
+
 // ---- selection ----
 // keys: sort_keys_bytes(P) bytes; scratch: sort_scratch_bytes(P) bytes.  Rows that would land in front of
 // `first_row` are not written (the selection below has placed them already).
@@ -93,14 +107,14 @@ size_t sort_scratch_bytes(uint32_t p);
 size_t sort_keys_bytes(uint32_t p);
 hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
                        float *vout, float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p,
-                       uint32_t d, uint32_t first_row = 0);
+                       uint32_t d, uint32_t first_row = 0, const SortExchange *exchange = nullptr);
 // the best `need` rows in order into rows 0..need-1 of the out arrays, other rows untouched; only
 // where select_applies() (otherwise hipErrorInvalidValue)
 bool select_applies(uint32_t p, uint32_t need);
 size_t select_scratch_bytes(uint32_t p); // the sort scratch must hold at least this much
 hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, const float *fin, float *vout,
                          float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p, uint32_t d, uint32_t need,
-                         uint32_t num_cus);
+                         uint32_t num_cus, const SortExchange *exchange = nullptr);
 
 // ---- island exchange ----
 hipError_t launch_pack_rows(hipStream_t st, const float *values, const float *steps, const float *fitness,

@@ -1202,6 +1202,34 @@ __global__ __launch_bounds__(kWave) void k_fitness(const float *__restrict__ spe
 // original index first (the CPU's stable order), NaN after every number.  Implemented as a
 // bitonic network over unique 64-bit keys (order-preserving fitness bits << 32 | index).
 // ------------------------------------------------------------------------------------
+// ---- island exchange inside the kernels that move the sorted rows (SortExchange, sots_kernels.h) -------------
+// a destination row that belongs to an immigrant: the local row that sorted there is NOT written
+__device__ __forceinline__ bool ex_immigrant_row(const SortExchange &ex, uint32_t dst)
+{
+    return ex.imm != nullptr && dst - ex.imm_first < ex.imm_rows;
+}
+// element `c` (0..d-1 values, d..2d-1 steps, 2d fitness) of destination row dst also goes to the packed elite rows
+__device__ __forceinline__ void ex_sink(const SortExchange &ex, uint32_t dst, uint32_t c, uint32_t d, float v)
+{
+    if (dst < ex.sink_rows) ex.sink[(size_t)dst * (2 * d + 1) + (c == 2 * d ? 0u : c + 1u)] = v;
+}
+// the immigrant rows themselves (k_unpack_rows' copy), by the threads of ONE workgroup
+__device__ __forceinline__ void ex_unpack(const SortExchange &ex, float *__restrict__ vout, float *__restrict__ sout,
+                                          float *__restrict__ fout, uint32_t d, uint32_t tid, uint32_t threads)
+{
+    if (ex.imm == nullptr) return;
+    const uint32_t w = 2 * d + 1, total = ex.imm_rows * w;
+    for (uint32_t e = tid; e < total; e += threads) {
+        const uint32_t r = e / w, c = e - r * w, dst = ex.imm_first + r;
+        const uint32_t sr = r < ex.skip_first ? r : r + ex.skip_count;
+        const float v = ex.imm[(size_t)sr * w + c]; // packed rows: [fitness, values.., steps..]
+        if (c == 0) fout[dst] = v;
+        else if (c <= d) vout[(size_t)dst * d + (c - 1)] = v;
+        else sout[(size_t)dst * d + (c - 1 - d)] = v;
+        if (dst < ex.sink_rows) ex.sink[(size_t)dst * w + c] = v;
+    }
+}
+
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kSortTile = 4096; // keys per LDS tile (32 KiB)
 constexpr uint32_t kSortSmall = 1024; // populations sorted by one workgroup in one launch (k_sort_small)
@@ -1438,9 +1466,10 @@ __global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64
                                                                     float *__restrict__ vout, float *__restrict__ sout,
                                                                     float *__restrict__ fout, uint32_t n_pad,
                                                                     uint32_t groups, uint32_t p_len, uint32_t d,
-                                                                    uint32_t first_row)
+                                                                    uint32_t first_row, SortExchange ex)
 {
     constexpr uint32_t kSlots = 64;
+    if (blockIdx.x == 0) ex_unpack(ex, vout, sout, fout, d, threadIdx.x, kRankThreads);
     __shared__ uint32_t part[4][kSlots];
     __shared__ uint32_t src_row[kSlots];
     const uint32_t j = threadIdx.x & (kSlots - 1), quarter = threadIdx.x / kSlots;
@@ -1457,9 +1486,12 @@ __global__ __launch_bounds__(kRankThreads) void k_sort_rank_scatter(const uint64
         if (src >= p_len) continue;
         const uint32_t dst = part[0][jj] + part[1][jj] + part[2][jj] + part[3][jj];
         if (dst < first_row) continue; // rows the selection kernels have already placed
-        if (c < d) vout[(size_t)dst * d + c] = vin[(size_t)src * d + c];
-        else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = sin[(size_t)src * d + (c - d)];
-        else fout[dst] = fin[src];
+        if (ex_immigrant_row(ex, dst)) continue;
+        const float v = c < d ? vin[(size_t)src * d + c] : c < 2 * d ? sin[(size_t)src * d + (c - d)] : fin[src];
+        if (c < d) vout[(size_t)dst * d + c] = v;
+        else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = v;
+        else fout[dst] = v;
+        ex_sink(ex, dst, c, d, v);
     }
 }
 
@@ -1469,16 +1501,20 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint64_t *__restrict_
                                                      const float *__restrict__ sin,
                                                      const float *__restrict__ fin, float *__restrict__ vout,
                                                      float *__restrict__ sout, float *__restrict__ fout,
-                                                     uint32_t p_len, uint32_t d, uint32_t first_row)
+                                                     uint32_t p_len, uint32_t d, uint32_t first_row, SortExchange ex)
 {
     const uint32_t w = 2 * d + 1;
     const uint32_t total = p_len * w;
+    if (blockIdx.x == 0) ex_unpack(ex, vout, sout, fout, d, threadIdx.x, blockDim.x);
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x + first_row * w; e < total; e += gridDim.x * blockDim.x) {
         const uint32_t r = e / w, c = e - r * w;
+        if (ex_immigrant_row(ex, r)) continue;
         const uint32_t src = (uint32_t)keys[r];
-        if (c < d) vout[r * d + c] = vin[src * d + c];
-        else if (c < 2 * d) sout[r * d + (c - d)] = sin[src * d + (c - d)];
-        else fout[r] = fin[src];
+        const float v = c < d ? vin[(size_t)src * d + c] : c < 2 * d ? sin[(size_t)src * d + (c - d)] : fin[src];
+        if (c < d) vout[(size_t)r * d + c] = v;
+        else if (c < 2 * d) sout[(size_t)r * d + (c - d)] = v;
+        else fout[r] = v;
+        ex_sink(ex, r, c, d, v);
     }
 }
 
@@ -1615,9 +1651,10 @@ template <uint32_t RUNS>
 __global__ __launch_bounds__(RUNS *kWave) void k_sort_small(const float *__restrict__ vin, const float *__restrict__ sin,
                                                             const float *__restrict__ fin, float *__restrict__ vout,
                                                             float *__restrict__ sout, float *__restrict__ fout,
-                                                            uint32_t p_len, uint32_t d, uint32_t first_row)
+                                                            uint32_t p_len, uint32_t d, uint32_t first_row, SortExchange ex)
 {
     __shared__ uint32_t runs[RUNS * kWave];
+    ex_unpack(ex, vout, sout, fout, d, threadIdx.x, RUNS * kWave);
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     uint32_t b = tid < p_len ? order_bits(fin[tid]) : kSelPadBits, i = tid;
@@ -1656,10 +1693,15 @@ __global__ __launch_bounds__(RUNS *kWave) void k_sort_small(const float *__restr
         for (uint32_t w = 0; w < RUNS; ++w) rank += pos[w] - w * kWave + (runs[pos[w]] < thr[w] ? 1u : 0u);
     }
     if (!real || rank < first_row) return; // padding keys sort behind every row
+    if (ex_immigrant_row(ex, rank)) return; // an immigrant's place
     fout[rank] = f;
+    ex_sink(ex, rank, 2 * d, d, f);
 #pragma unroll
     for (uint32_t c = 0; c < 4; ++c)
-        if (c < d) vout[rank * d + c] = v4[c], sout[rank * d + c] = s4[c];
+        if (c < d) {
+            vout[rank * d + c] = v4[c], sout[rank * d + c] = s4[c];
+            ex_sink(ex, rank, c, d, v4[c]), ex_sink(ex, rank, d + c, d, s4[c]);
+        }
     for (uint32_t c0 = 4; c0 < d; c0 += 4) { // wider voices: four more genes per trip
 #pragma unroll
         for (uint32_t c = 0; c < 4; ++c) {
@@ -1668,7 +1710,10 @@ __global__ __launch_bounds__(RUNS *kWave) void k_sort_small(const float *__restr
         }
 #pragma unroll
         for (uint32_t c = 0; c < 4; ++c)
-            if (c0 + c < d) vout[rank * d + c0 + c] = v4[c], sout[rank * d + c0 + c] = s4[c];
+            if (c0 + c < d) {
+                vout[rank * d + c0 + c] = v4[c], sout[rank * d + c0 + c] = s4[c];
+                ex_sink(ex, rank, c0 + c, d, v4[c]), ex_sink(ex, rank, d + c0 + c, d, s4[c]);
+            }
     }
 }
 
@@ -1740,9 +1785,10 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
                                                                   const float *__restrict__ fin,
                                                                   float *__restrict__ vout, float *__restrict__ sout,
                                                                   float *__restrict__ fout, uint32_t tiles, uint32_t need,
-                                                                  uint32_t p_len, uint32_t d)
+                                                                  uint32_t p_len, uint32_t d, SortExchange ex)
 {
     constexpr uint32_t kWaves = kSelThreads / kWave;
+    if (blockIdx.x == 0) ex_unpack(ex, vout, sout, fout, d, threadIdx.x, kSelThreads);
     // the names of the 1024 / 256 layout, shadowed by this instantiation's values
     constexpr uint32_t kSelTile = TILE, kSelQuantum = QUANT, kSelSamples = TILE / QUANT;
     // a tile whose prefix STARTS inside the window fits whole, skew included (at most window / QUANT tiles per pass)
@@ -1971,13 +2017,14 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
         const uint32_t slot = r * kSelKeysPerRound + tid / kSelLanesPerKey;
         if (slot >= share || own_tile[slot] == 0xFFFFFFFFu) continue;
         const uint32_t dst = own_rank[slot];
-        if (dst >= need) continue;
+        if (dst >= need || ex_immigrant_row(ex, dst)) continue;
 #pragma unroll
         for (uint32_t q = 0; q < kColsPerLane; ++q) {
             const uint32_t c = sub + q * kSelLanesPerKey;
             if (c < d) vout[(size_t)dst * d + c] = val[r][q];
             else if (c < 2 * d) sout[(size_t)dst * d + (c - d)] = val[r][q];
             else if (c < width) fout[dst] = val[r][q];
+            if (c < width) ex_sink(ex, dst, c, d, val[r][q]);
         }
     }
     SOTS_PHASE(7);
@@ -2585,16 +2632,17 @@ size_t sort_scratch_bytes(uint32_t p)
 
 hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const float *fin,
                        float *vout, float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p,
-                       uint32_t d, uint32_t first_row)
+                       uint32_t d, uint32_t first_row, const SortExchange *exchange)
 {
+    const SortExchange ex = exchange ? *exchange : SortExchange{};
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
     if (n_pad <= kSortSmall) { // one launch
         switch ((n_pad + kWave - 1) / kWave) {
-        case 1: k_sort_small<1><<<1, 1 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
-        case 2: k_sort_small<2><<<1, 2 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
-        case 4: k_sort_small<4><<<1, 4 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
-        case 8: k_sort_small<8><<<1, 8 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
-        default: k_sort_small<16><<<1, 16 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row); break;
+        case 1: k_sort_small<1><<<1, 1 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row, ex); break;
+        case 2: k_sort_small<2><<<1, 2 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row, ex); break;
+        case 4: k_sort_small<4><<<1, 4 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row, ex); break;
+        case 8: k_sort_small<8><<<1, 8 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row, ex); break;
+        default: k_sort_small<16><<<1, 16 * kWave, 0, st>>>(vin, sin, fin, vout, sout, fout, p, d, first_row, ex); break;
         }
         return hipGetLastError();
     }
@@ -2617,7 +2665,7 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
         const uint32_t runs = n_pad / kRankLdsKeys;
         k_sort_rank_pairs<1><<<dim3(runs, runs), kRankThreads, 0, st>>>(merged, partial, n_pad, kRankLdsKeys);
         k_sort_rank_scatter<<<n_pad / 64, kRankThreads, 0, st>>>(merged, partial, vin, sin, fin, vout, sout, fout,
-                                                               n_pad, runs, p, d, first_row);
+                                                               n_pad, runs, p, d, first_row, ex);
         return hipGetLastError();
     }
     if (rank_merge) {
@@ -2630,7 +2678,7 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
         default: k_sort_rank_pairs<1><<<dim3(tiles, groups), kRankThreads, 0, st>>>(keys, partial, n_pad, tile); break;
         }
         k_sort_rank_scatter<<<n_pad / 64, kRankThreads, 0, st>>>(keys, partial, vin, sin, fin, vout, sout, fout,
-                                                               n_pad, groups, p, d, first_row);
+                                                               n_pad, groups, p, d, first_row, ex);
         return hipGetLastError();
     }
     for (uint32_t k = tile << 1; k <= n_pad && k != 0; k <<= 1) {
@@ -2639,7 +2687,7 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
         k_sort_tile_merge<<<tiles, threads, 0, st>>>(keys, k, tile);
     }
     k_sort_gather<<<grid_for((uint64_t)p * (2 * d + 1), 256), 256, 0, st>>>(keys, vin, sin, fin, vout, sout,
-                                                                            fout, p, d, first_row);
+                                                                            fout, p, d, first_row, ex);
     return hipGetLastError();
 }
 
@@ -2672,9 +2720,10 @@ size_t select_scratch_bytes(uint32_t p)
 
 hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, const float *fin, float *vout,
                          float *sout, float *fout, uint64_t *keys, void *scratch, uint32_t p, uint32_t d, uint32_t need,
-                         uint32_t num_cus)
+                         uint32_t num_cus, const SortExchange *exchange)
 {
     if (!select_applies(p, need)) return hipErrorInvalidValue;
+    const SortExchange ex = exchange ? *exchange : SortExchange{};
     const uint32_t n_pad = next_pow2(p);
     const uint32_t tiles = n_pad / kSelTile;
     uint32_t *kbits = reinterpret_cast<uint32_t *>(keys), *kidx = kbits + n_pad, *samples = kidx + n_pad;
@@ -2686,7 +2735,7 @@ hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, con
     if (grid < min_grid) grid = min_grid;
     // lanes per key x 8 search chains = the tiles one pass stages: 64 / 32 / 16 tiles of 1024 keys, <= 20 big tiles
 #define SOTS_SEL(R, T, Q, L, KB, KI, SM, NT) \
-    k_sel_rank_scatter<R, T, Q, L><<<grid, kSelThreads, 0, st>>>(KB, KI, SM, vin, sin, fin, vout, sout, fout, NT, need, p, d)
+    k_sel_rank_scatter<R, T, Q, L><<<grid, kSelThreads, 0, st>>>(KB, KI, SM, vin, sin, fin, vout, sout, fout, NT, need, p, d, ex)
     if (tiles <= kSelDirectTiles) {
         switch (tiles * kSelSamples / kWave) {
         case 1: SOTS_SEL(1, kSelTile, kSelQuantum, 2, kbits, kidx, samples, tiles); break;

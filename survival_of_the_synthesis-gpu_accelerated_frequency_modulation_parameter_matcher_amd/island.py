@@ -30,6 +30,15 @@ class IslandExchange:
         self.all = [torch.empty(world * num_elites, self.width, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         self.cur = 0
         self.pending = None  # (work handle, buffer index) of the collective in flight
+        # generation(): the overlapped all-gather runs on a side stream; the HOST waits for it (arrived event) right before it
+        # enqueues the sort that takes its rows, so the island's stream never waits for an event of another stream (on this
+        # runtime that costs the waiting stream ~18 us per generation, tools/ubench/cross_stream.hip)
+        self.exchanges = 0
+        self.side = None
+        if self.device.type == "cuda" and world > 1:
+            self.side = torch.cuda.Stream(device=self.device)
+            self.packed = [torch.cuda.Event(), torch.cuda.Event()]
+            self.arrived = [torch.cuda.Event(), torch.cuda.Event()]
 
     @property
     def num_immigrants(self) -> int:
@@ -70,8 +79,51 @@ class IslandExchange:
         if self.pending is not None:
             self.pending[0].wait()
             self.pending = None
+        if self.side is not None:
+            self.side.synchronize()
+
+    def restart(self) -> None:
+        """A new population (init_population): no rows in flight, exchange counting starts again."""
+        self.finish()
+        self.exchanges = 0
+        self.cur = 0
 
     # ---- device path: rows never leave HBM -------------------------------------------------
+    def generation(self, es) -> None:
+        """One generation of `es` (a HipES whose stream is the current torch stream) and its exchange, with pack and
+        inject folded into the generation's sort kernel (sots_fuse_exchange_next_sort) instead of a launch each:
+        the same rows at the same places as execute_generations(1) + migrate_device(es)."""
+        if self.world == 1:
+            es.execute_generations(1)
+            return
+        if not es.sort_places(self.E):  # elites beyond the rows the sort places: the separate launches
+            es.execute_generations(1)
+            self.migrate_device(es)
+            return
+        if not self.overlap:
+            es.fuse_exchange_next_sort(self.mine[0].data_ptr(), self.E, None, self.world, self.rank, self.E)
+            es.execute_generations(1)
+            self._all_gather(0, async_op=False)
+            es.inject_gathered_device(self.all[0].data_ptr(), self.world, self.rank, self.E)
+            return
+        # overlapped: exchange x (buffers x & 1) takes the rows gathered at exchange x - 1.  The host waits for that
+        # collective inside execute_generations, right before the sort is enqueued (by then this generation's variation,
+        # synthesis and spectral kernels are on the stream); having seen exchange x - 1 complete, which ran behind exchange
+        # x - 2 on the side stream, also frees mine[x & 1] (filled at exchange x - 2) for this sort to overwrite
+        x, idx = self.exchanges, self.exchanges & 1
+        if x > 0:
+            es.fuse_exchange_next_sort(self.mine[idx].data_ptr(), self.E, self.all[idx ^ 1].data_ptr(), self.world, self.rank, self.E,
+                                       self.arrived[idx ^ 1].cuda_event)
+        else:
+            es.fuse_exchange_next_sort(self.mine[idx].data_ptr(), self.E, None, self.world, self.rank, self.E)
+        es.execute_generations(1)
+        self.packed[idx].record()  # on the island's stream: mine[idx] is complete
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.packed[idx])
+            self._all_gather(idx, async_op=False)  # the SIDE stream waits for the collective; the host does not (gloo: it does)
+            self.arrived[idx].record()
+        self.exchanges += 1
+
     def migrate_device(self, es) -> None:
         """es: HipES whose stream is the current torch stream."""
         self._exchange(lambda i: es.pack_elites_device(self.mine[i].data_ptr(), self.E),

@@ -18,6 +18,7 @@ PKG = "survival_of_the_synthesis-gpu_accelerated_frequency_modulation_parameter_
 def main():
     out_dir, gens, elites, overlap = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) != 0
     parents, offspring = int(sys.argv[5]), int(sys.argv[6])
+    fused = len(sys.argv) > 7 and int(sys.argv[7]) != 0  # pack + inject inside the sort kernel (IslandExchange.generation)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module(PKG)
@@ -35,8 +36,11 @@ def main():
     with torch.cuda.stream(stream):
         es.init_population(0)
         for _ in range(gens):
-            es.execute_generations(1)
-            ex.migrate_device(es)
+            if fused:
+                ex.generation(es)
+            else:
+                es.execute_generations(1)
+                ex.migrate_device(es)
         ex.finish()
     torch.cuda.synchronize(device)
     v, s, f = es.read_population()

@@ -99,7 +99,7 @@ def test_plain_command_with_several_gpus_starts_the_ranks_before_touching_torch_
         "    seen['torch_imported'] = 'torch' in sys.modules\n"
         "    seen['hip_library_open'] = any('libsots_hip' in l for l in open('/proc/self/maps'))\n"
         "    seen['ipc'] = (env or {}).get('HSA_ENABLE_IPC_MODE_LEGACY')\n"
-        "    class R: returncode = 7\n"
+        "    class R: returncode = 7; stdout = 'gloo banner\\n{\\\"relayed\\\": 1}\\n'\n"
         "    return R()\n"
         "bench.subprocess.run = fake_run\n"
         "try:\n"
@@ -110,6 +110,8 @@ def test_plain_command_with_several_gpus_starts_the_ranks_before_touching_torch_
     out = subprocess.run([sys.executable, str(probe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     seen = json.loads(out.stdout.strip().splitlines()[-1])
+    # only the ranks' JSON line is relayed on stdout; what else they print (gloo's banner) goes to stderr
+    assert '{"relayed": 1}' in out.stdout and "gloo banner" not in out.stdout and "gloo banner" in out.stderr
     assert seen["torch_imported"] is False and seen["hip_library_open"] is False
     assert seen["exit"] == 7  # the ranks' return code is ours
     cmd = seen["cmd"]

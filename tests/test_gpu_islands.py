@@ -55,8 +55,12 @@ def simulate(pkg, target, world, gens, elites, overlap, parents, offspring):
 
 # 2048 + 6144: the six-launch loop (variation kernel + cut synthesis); 49152 + 16384 with world 2 would be
 # the fused-variation loop but is left to bench.py's rehearsal - the exchange code is the same
-@pytest.mark.parametrize("world,overlap,parents,offspring", [(2, 0, 2048, 6144), (2, 1, 2048, 6144), (3, 1, 96, 160), (3, 0, 80, 176)])
-def test_migrate_device_across_processes_equals_host_exchange(tmp_path, pkg, O, world, overlap, parents, offspring):
+# fused = 1: IslandExchange.generation (pack and inject inside the generation's sort kernel, what bench.py runs);
+# 4096 + 12288 takes the selection kernels, the small ones k_sort_small, 2048 + 6144 the tile sort + rank scatter
+@pytest.mark.parametrize("world,overlap,parents,offspring,fused", [
+    (2, 0, 2048, 6144, 0), (2, 1, 2048, 6144, 0), (3, 1, 96, 160, 0), (3, 0, 80, 176, 0),
+    (2, 0, 2048, 6144, 1), (2, 1, 2048, 6144, 1), (3, 1, 96, 160, 1), (3, 0, 80, 176, 1), (2, 1, 4096, 12288, 1), (3, 0, 4096, 12288, 1)])
+def test_migrate_device_across_processes_equals_host_exchange(tmp_path, pkg, O, world, overlap, parents, offspring, fused):
     gens, elites = 6, 16
     target = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, PMAX, 1024)
     np.save(tmp_path / "target.npy", target)
@@ -66,7 +70,7 @@ def test_migrate_device_across_processes_equals_host_exchange(tmp_path, pkg, O, 
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_island_gpu_worker.py"), str(tmp_path),
-                                       str(gens), str(elites), str(overlap), str(parents), str(offspring)], env=env,
+                                       str(gens), str(elites), str(overlap), str(parents), str(offspring), str(fused)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=600)
@@ -120,15 +124,18 @@ def test_one_device_group_is_the_plain_context(pkg, O):
         g.close()
 
 
-@pytest.mark.parametrize("world,overlap,interval", [(2, False, 1), (2, True, 1), (3, False, 2), (3, True, 1)])
-def test_group_of_islands_sharing_the_gpu_equals_host_exchange(pkg, O, world, overlap, interval):
+# unfused: 0 = pack and inject inside the sort kernel, overlapped schedule with ready counters polled by that kernel (default);
+# 1 = launches of their own; 2 = fused, but ordered by HIP events instead of the counters
+@pytest.mark.parametrize("parents,offspring,unfused", [(2048, 6144, 0), (2048, 6144, 1), (4096, 12288, 0), (96, 160, 0), (4096, 12288, 2)])
+@pytest.mark.parametrize("world,overlap,interval", [(2, False, 1), (2, True, 1), (3, False, 2), (3, True, 1), (3, True, 2)])
+def test_group_of_islands_sharing_the_gpu_equals_host_exchange(pkg, O, world, overlap, interval, parents, offspring, unfused):
     """Several islands of one group on device 0 (event-ordered device-to-device copies stand in for RCCL, which
     refuses two ranks on one GPU): island threads, double-buffered exchange and both schedules against the
     single-threaded host-exchange simulation."""
-    parents, offspring, gens, elites = 2048, 6144, 6, 16
+    gens, elites = 6, 16
     target = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, PMAX, 1024)
     g = pkg.HipGroup([0] * world, elites, parents, offspring, pkg.capi.SYNTH_2OP, 10, None, PMAX, seed=0x5EED0001,
-                     migration_interval=interval, overlap=overlap)
+                     migration_interval=interval, overlap=overlap, unfused=unfused == 1, event_waits=unfused == 2)
     assert g.size == world and not g.uses_rccl
     g.set_target_audio(target)
     g.init_population(0)
