@@ -343,32 +343,45 @@ template <int V> using ic = std::integral_constant<int, V>;
 // SPLIT2 > SPLIT: a second cut in front of operator SPLIT2 - three wavefronts per 64 individuals (stages of operators
 // [0, SPLIT), [SPLIT, SPLIT2), [SPLIT2, OPS)), two hand-over links; for the 4-operator voice at <= 128 individuals per CU
 // where a series chain of OPS operators is cut, as compile-time facts
-template <int SPLIT, int SPLIT2, int OPS> struct CutPlan {
-    static constexpr int STAGES = 1 + (SPLIT > 0 ? 1 : 0) + (SPLIT2 > 0 ? 1 : 0);
+// SPLIT3 > SPLIT2: a third cut - with SPLIT = 1, 2, 3 every operator of the 4-operator voice has a wavefront of its own,
+// four wavefronts per 64 individuals and three links: eight wavefronts for the 128 individuals per CU of BASELINE configs[3]'s
+// shard, two per SIMD (one wavefront alone on a SIMD issues an instruction every ~4.5 cycles, two sharing it every ~2.3).
+// The 32 KiB beside the table then hold 2 tiles of 4 KiB (16 samples, leaving as half lines) and 6 hand-over buffers of
+// 4 KiB (two 8-sample blocks each).
+template <int SPLIT, int SPLIT2, int SPLIT3, int OPS> struct CutPlan {
+    static constexpr int STAGES = 1 + (SPLIT > 0 ? 1 : 0) + (SPLIT2 > 0 ? 1 : 0) + (SPLIT3 > 0 ? 1 : 0);
+    static constexpr int cuts_before(int S) { return (SPLIT > 0 && S >= SPLIT ? 1 : 0) + (SPLIT2 > 0 && S >= SPLIT2 ? 1 : 0) + (SPLIT3 > 0 && S >= SPLIT3 ? 1 : 0); }
     // stage of operator S: 0 = the chain's head ... STAGES-1 = its tail (which also owns the tile)
-    static constexpr int stage_of(int S) { return SPLIT == 0 ? 0 : S < SPLIT ? 0 : (SPLIT2 > 0 && S >= SPLIT2) ? 2 : 1; }
+    static constexpr int stage_of(int S) { return cuts_before(S); }
     // In trip k operator S works on block k - slot(S): one trip behind the operator in front of it, TWO behind it
     // across a cut (the stage in front sends a block in the trip AFTER it read the table for it, when the values
     // have landed, and the block is read in the trip after that); block k - slot(OPS) leaves.
-    static constexpr int slot(int S) { return S + (SPLIT > 0 && S >= SPLIT ? 1 : 0) + (SPLIT2 > 0 && S >= SPLIT2 ? 1 : 0); }
-    static constexpr bool consumes(int S) { return SPLIT > 0 && S > 0 && (S == SPLIT || S == SPLIT2); }
-    static constexpr bool produces(int S) { return SPLIT > 0 && S + 1 < OPS && (S + 1 == SPLIT || S + 1 == SPLIT2); }
+    static constexpr int slot(int S) { return S + cuts_before(S); }
+    static constexpr bool is_cut(int S) { return S > 0 && (S == SPLIT || S == SPLIT2 || S == SPLIT3); }
+    static constexpr bool consumes(int S) { return SPLIT > 0 && is_cut(S); }
+    static constexpr bool produces(int S) { return SPLIT > 0 && S + 1 < OPS && is_cut(S + 1); }
+    // samples per pipeline block and 16-byte chunks per tile row: the deepest cut has the least LDS per buffer
+    static constexpr int U = SPLIT == 0 ? kSynthUnroll : STAGES >= 4 ? 8 : kSynthUnrollCut;
+    static constexpr int CH = STAGES >= 4 ? 4 : kStageChunks;
 };
 
-template <int KIND, int SPLIT, bool HELP = false, int SPLIT2 = 0>
-__global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave) void k_synth(const float *__restrict__ values,
+template <int KIND, int SPLIT, bool HELP = false, int SPLIT2 = 0, int SPLIT3 = 0>
+__global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 : 4) * kWave) void k_synth(const float *__restrict__ values,
                                                                const float *__restrict__ wavetable,
                                                                float *__restrict__ audio, SynthParams sp,
                                                                uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
 {
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
-    constexpr int U = SPLIT > 0 ? kSynthUnrollCut : kSynthUnroll;
-    static_assert(U % 4 == 0 && 4 * kStageChunks % U == 0, "whole 16-byte chunks, whole blocks per flush");
+    using Plan = CutPlan<SPLIT, SPLIT2, SPLIT3, OPS>;
+    constexpr int U = Plan::U;
+    constexpr int CH = Plan::CH;        // 16-byte chunks per tile row = 4 CH samples per flush
+    constexpr int RPI = kWave / CH;     // rows per transposed read / store instruction (CH of them per flush)
+    static_assert(U % 4 == 0 && 4 * CH % U == 0, "whole 16-byte chunks, whole blocks per flush");
     static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
     static_assert(SPLIT2 == 0 || (SPLIT > 0 && SPLIT2 > SPLIT && SPLIT2 < OPS), "the second cut lies behind the first");
+    static_assert(SPLIT3 == 0 || (SPLIT2 > 0 && SPLIT3 > SPLIT2 && SPLIT3 < OPS), "the third cut lies behind the second");
     static_assert(!HELP || SPLIT > 0 || D == 4, "uncut, the helper wavefronts serve the 4-gene voice (128 registers with 16 wavefronts)");
     constexpr uint32_t HT = 4; // HELP: threads per individual while the genes are made (each takes genes t % 4, t % 4 + 4, ...)
-    using Plan = CutPlan<SPLIT, SPLIT2, OPS>;
     constexpr int STAGES = Plan::STAGES;
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
@@ -407,24 +420,27 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
         }
     }
     const uint32_t rho = SPLIT ? wave_id / pairs : 0u;          // 0: tail stage
-    const int my_stage = STAGES - 1 - (int)rho;
+    const int my_stage = STAGES - 1 - (int)rho; // (pairing the tail with the head stage on a SIMD instead: no difference, profiles/r03_experiments.md)
     const bool front = my_stage != STAGES - 1;                  // not the tail: no tile, no stores
     const uint32_t wave = wave_id - rho * pairs;                // which 64 individuals of the workgroup's tile
-    float4 *__restrict__ stage = stage_all + wave * kWave * kStageChunks;
+    float4 *__restrict__ stage = stage_all + wave * kWave * CH;
     // hand-over buffers [link][pair][parity][U/4][lane] of 16 bytes behind the tiles of a cut kernel (launch_synth keeps
-    // pairs * (tile + links * hand-over buffer) inside stage_all: two pairs with one link, one pair with two)
-    float4 *__restrict__ xbuf0 = stage_all + pairs * kWave * kStageChunks + wave * (2 * (U / 4) * kWave);
+    // pairs * (tile + links * hand-over buffer) inside stage_all: two pairs with one link, one pair with two, two pairs
+    // with three links of half-length blocks and half-length tiles)
+    float4 *__restrict__ xbuf0 = stage_all + pairs * kWave * CH + wave * (2 * (U / 4) * kWave);
     float4 *__restrict__ xbuf1 = xbuf0 + pairs * (2 * (U / 4) * kWave);
-    // write side: lane = row; chunk q of the row lives in slot q ^ (row & 7)
-    float4 *__restrict__ wr = stage + lane * kStageChunks;
-    const uint32_t l7 = lane & 7u;
-    // read side: lane = (row & 7 within a group of 8 rows, chunk): group `it` adds 64 slots
-    const uint32_t r8 = lane >> 3;
-    const float4 *__restrict__ rd = stage + r8 * kStageChunks + (l7 ^ r8);
-    const uint32_t lane_off = r8 * pitch + 4u * l7; // floats, relative to the group's first row
-    uint32_t row_off[8];                            // ... and, in BYTES, of this lane's line in each of the eight groups of 8 rows
+    float4 *__restrict__ xbuf2 = xbuf1 + pairs * (2 * (U / 4) * kWave);
+    // write side: lane = row; chunk q of the row lives in slot q ^ swz(row): row & 7 with eight chunks, (row >> 1) & 3 with four
+    auto swz = [](uint32_t row) { return CH == 8 ? (row & 7u) : ((row >> 1) & 3u); };
+    float4 *__restrict__ wr = stage + lane * CH;
+    const uint32_t l7 = swz(lane);
+    // read side: lane = (row within a group of RPI rows, chunk): group `it` adds 64 slots
+    const uint32_t r8 = lane / CH, rch = lane % CH;
+    const float4 *__restrict__ rd = stage + r8 * CH + (rch ^ swz(r8)); // (RPI is a multiple of what swz looks at: the group index drops out)
+    const uint32_t lane_off = r8 * pitch + 4u * rch; // floats, relative to the group's first row
+    uint32_t row_off[CH];                           // ... and, in BYTES, of this lane's piece of a line in each of the CH groups of RPI rows
 #pragma unroll
-    for (uint32_t g = 0; g < 8; ++g) row_off[g] = (lane_off + g * 8u * pitch) * 4u; // < 2^32: 64 rows of at most 8224 floats
+    for (uint32_t g = 0; g < (uint32_t)CH; ++g) row_off[g] = (lane_off + g * RPI * pitch) * 4u; // < 2^32: 64 rows of at most 8224 floats
 
     const uint32_t rows_per_block = pairs * kWave;
     float help_next[HELP ? D : 1]; // HELP: the second tile's values
@@ -512,8 +528,8 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
 
             // Schedule (CutPlan): operator S works on block k - slot(S) in trip k.  A block's parity (which half of T,
             // which hand-over buffer) is its index & 1.
-            // link = the producer's stage: operators [0, SPLIT) send through xbuf0, [SPLIT, SPLIT2) through xbuf1
-            auto link_of = [&](int producer) -> float4 * { return (SPLIT2 > 0 && producer >= SPLIT) ? xbuf1 : xbuf0; };
+            // link = the producer's stage: stage 0 sends through xbuf0, stage 1 through xbuf1, stage 2 through xbuf2
+            auto link_of = [&](int producer) -> float4 * { return Plan::stage_of(producer) == 0 ? xbuf0 : Plan::stage_of(producer) == 1 ? xbuf1 : xbuf2; };
 
             // the increments of operator S's block (parity B), asked for at the start of the trip
             auto fetch = [&](auto s_tag, auto b_tag) {
@@ -584,7 +600,7 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
             };
             // a tile on its way out: eight rows x 128-byte lines per store instruction, the address a wavefront-uniform
             // line start plus a per-lane offset that never changes (no vector address arithmetic per flush)
-            float pend[8][4]; // (plain floats: an array of float4 does not leave memory for registers)
+            float pend[CH][4]; // (plain floats: an array of float4 does not leave memory for registers)
             float *__restrict__ pend_line = audio;
             bool pending = false;
             auto store_pending = [&]() {
@@ -592,7 +608,7 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
                 if (!pending) return;
                 pending = false;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
+                for (int g = 0; g < CH; ++g) {
                     asm volatile("" : "+v"(row_off[g])); // the zero-extension stays next to the store: scalar base + 32-bit lane offset
                     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(pend_line) + row_off[g]) = make_float4(pend[g][0], pend[g][1], pend[g][2], pend[g][3]);
                 }
@@ -611,24 +627,24 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
                         y[u] = T[OPS - 1][B][0][u] * gain[0];
                 }
                 store_pending(); // the tile read back one trip ago leaves now: its LDS reads have long landed
-                const uint32_t c0 = (ip >> 2) & (kStageChunks - 1);
+                const uint32_t c0 = (ip >> 2) & (CH - 1);
 #pragma unroll
                 for (int q = 0; q < U / 4; ++q) wr[(c0 + q) ^ l7] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
 #ifdef SOTS_ABL_NOFLUSH
                 if (false) {
 #else
-                if (c0 == kStageChunks - U / 4) { // 32 samples parked: flush the tile
+                if (c0 == CH - U / 4) { // 4 CH samples parked: flush the tile
 #endif
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
-                    const uint32_t i0 = ip + U - 4 * kStageChunks;
+                    const uint32_t i0 = ip + U - 4 * CH;
                     float *__restrict__ line0 = audio + (size_t)row0 * pitch + i0; // wavefront-uniform
                     if (full) {
                         // read back transposed now (LDS works in order: the next samples are parked behind these
                         // reads), stored in the next trip
-                        constexpr int G = 8 * kStageChunks; // slots per group of 8 rows
+                        constexpr int G = RPI * CH; // slots per group of RPI rows (= 64)
 #pragma unroll
-                        for (int g = 0; g < 8; ++g) {
+                        for (int g = 0; g < CH; ++g) {
                             const float4 q = rd[g * G];
                             pend[g][0] = q.x, pend[g][1] = q.y, pend[g][2] = q.z, pend[g][3] = q.w;
                         }
@@ -636,9 +652,9 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
                         pending = true;
                     } else { // last, partly filled tile of the population
 #pragma unroll 1
-                        for (uint32_t it = 0; it < kWave / 8; ++it)
-                            if (row0 + 8u * it + r8 < p_len)
-                                *reinterpret_cast<float4 *>(line0 + lane_off + (size_t)(8u * it) * pitch) = rd[it * 8 * kStageChunks];
+                        for (uint32_t it = 0; it < (uint32_t)CH; ++it)
+                            if (row0 + RPI * it + r8 < p_len)
+                                *reinterpret_cast<float4 *>(line0 + lane_off + (size_t)(RPI * it) * pitch) = rd[it * RPI * CH];
                     }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
@@ -698,7 +714,8 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT2 ? 6 : 4) * kWave)
             if constexpr (STAGES == 1) run(unclamped_tag, ic<0>{});
             else if (my_stage == 0) run(unclamped_tag, ic<0>{});
             else if (STAGES == 2 || my_stage == 1) run(unclamped_tag, ic<1>{});
-            else run(unclamped_tag, ic<(STAGES > 2 ? 2 : 0)>{});
+            else if (STAGES == 3 || my_stage == 2) run(unclamped_tag, ic<(STAGES > 2 ? 2 : 0)>{});
+            else run(unclamped_tag, ic<(STAGES > 3 ? 3 : 0)>{});
         };
         if (free_unclamped) run_my_stage(std::true_type{});
         else run_my_stage(std::false_type{});
@@ -2461,7 +2478,12 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         // up to 64 individuals per CU cut twice - operators {0, 1} | {2} | {3}, three wavefronts on three SIMDs (190 against
         // 215 us at P = 16384, N = 4096); with two groups per CU six wavefronts would share four SIMDs (279 against 258)
         if (cut && waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 2, false, 3><<<grid, 3 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+#ifndef SOTS_SYNTH_NO_CUT3
+        // 65 ... 128 individuals per CU: a wavefront per operator, eight per CU, two per SIMD (BASELINE configs[3]'s shard)
+        else if (cut) k_synth<SOTS_SYNTH_4OP_SERIES, 1, false, 2, 3><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+#else
         else if (cut) k_synth<SOTS_SYNTH_4OP_SERIES, 2><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+#endif
         else k_synth<SOTS_SYNTH_4OP_SERIES, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
         break;
     case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); break;

@@ -585,6 +585,30 @@ def full_size_properties(pkg, O, parents, offspring, kind, log2n):
     es.close()
 
 
+@pytest.mark.parametrize("parents,offspring,log2n", [(8192, 24576, 10), (8160, 24512, 9), (4128, 12352, 10)])
+def test_synthesise_four_op_one_wavefront_per_operator_bitexact(pkg, O, parents, offspring, log2n):
+    """65 ... 128 individuals per CU (BASELINE configs[3]'s shard: 32768 on 256 CUs): the 4-operator chain is cut in
+    front of every operator - k_synth<4OP, 1, false, 2, 3>: four wavefronts per 64 individuals, eight per CU, three
+    hand-over links of 8-sample blocks, 16-sample tiles that leave as half lines.  Rows are spot-checked bit for bit
+    against the oracle, the partly filled last tile (P = 32672: 32 rows in the last workgroup) and the
+    second group of a workgroup included; the variation folded into the same launch gives the same audio."""
+    kind = 3
+    es, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    es.init_population(0)
+    v, s, _ = es.read_population()
+    _, tv = target_audio(O, kind, es.N)
+    v[0], v[1], v[2] = tv, 0.0, 1.0
+    es.write_population(v, s, None)
+    es.synthesise()
+    audio = es.read_audio()
+    rng = np.random.default_rng(23)
+    rows = np.unique(np.concatenate([[0, 1, 2, 63, 64, 65, 127, 128, 191, 192, es.P - 33, es.P - 32, es.P - 1],
+                                     rng.choice(es.P, 100, replace=False)]))
+    for r in rows:
+        assert np.array_equal(audio[r], O.synth(kind, v[r], [0.0] * es.D, PMAX[kind], es.N)), f"row {r}"
+    es.close()
+
+
 def test_full_size_properties_config2(pkg, O):
     """BASELINE configs[2]: P = 65536 (16384 + 49152), 2-op, N = 1024, one GPU."""
     full_size_properties(pkg, O, 16384, 49152, 0, 10)
