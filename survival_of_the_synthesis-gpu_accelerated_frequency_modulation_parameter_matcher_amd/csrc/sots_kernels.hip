@@ -964,6 +964,9 @@ __device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], fl
                                             const float2 *__restrict__ tw, const float2 (&twr)[tw_count<M>()], int lane,
                                             float2 (&x)[M / kWave])
 {
+// (the workgroup is one wavefront: the compiler drops the s_barrier and keeps the fence, s_waitcnt lgkmcnt(0); ordering
+// the LDS accesses by a compiler barrier alone - the LDS executes a wavefront's instructions in order - measures the same,
+// profiles/r03_experiments.md)
 #define SOTS_SYNC() __syncthreads()
 #define SOTS_FIRST(R)                        \
     fft_first_pass<M, R>(q, lds, lane);      \
@@ -1562,9 +1565,9 @@ constexpr uint32_t kSelTile = 1024, kSelSamples = 4, kSelQuantum = kSelTile / kS
 constexpr uint32_t kSelThreads = 1024, kSelLanesPerKey = 8, kSelKeysPerRound = kSelThreads / kSelLanesPerKey;
 constexpr uint32_t kSelCap = 35328;                 // staged keys per pass: 138 KiB of LDS
 constexpr uint32_t kSelSkew = 4;                    // consecutive tiles start 4 more words (16 B) off the 1 KiB grid, see below
-// the rank kernel handles 16..128 tiles of either size: 1024-key tiles up to P = 65536, four-by-four merged tiles of 4096
-// keys up to P = 262144 (select_applies); with 256 unmerged tiles the k-th-sample search (quadratic in the tile count)
-// and four or more LDS passes cost more than the two-level full sort (170 against 88 us at P = 262144)
+// the rank kernel handles 16..64 tiles of 1024 keys (P <= 65536) and, for P = 131072, 32 tiles of 4096 keys merged four by
+// four (k_sel_merge4).  Same-box A/B of the un-instrumented loop (profiles/r03_experiments.md): at P = 131072 the selection
+// beats the two-level full sort (237 against 244 us per generation), at 262144 it loses (496 against 482), so it stops at 128 tiles
 constexpr uint32_t kSelMinTiles = 16, kSelMaxTiles = 128, kSelMaxOwn = 512; // kSelMaxTiles: tiles the rank kernel handles (of either size)
 
 // order-preserving bits of a fitness: every number (at most 0xFF800000, +inf) below NaN (0xFFFFFFFD), NaN
@@ -2461,7 +2464,7 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES, 2, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); return hipGetLastError();
         case SOTS_SYNTH_4OP_SERIES:
             if (waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 2, true, 3><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
-            else k_synth<SOTS_SYNTH_4OP_SERIES, 2, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+            else k_synth<SOTS_SYNTH_4OP_SERIES, 1, true, 2, 3><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); // (all eight wavefronts stay)
             return hipGetLastError();
         default: break;
         }
@@ -2725,7 +2728,7 @@ size_t sort_keys_bytes(uint32_t p)
 // (beyond that nearly everything would be staged and the full sort is the better plan).  Up to 64 tiles (P <= 65536)
 // the rank kernel works on the 1024-key tiles; from 128 to 256 tiles (P <= 262144) they are first merged four by four
 // (k_sel_merge4), which quarters its work; larger populations take the two-level full sort.
-constexpr uint32_t kSelDirectTiles = 64, kSelMergedTiles = 256;
+constexpr uint32_t kSelDirectTiles = 64, kSelMergedTiles = 128;
 bool select_applies(uint32_t p, uint32_t need)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
@@ -2771,7 +2774,6 @@ hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, con
         k_sel_merge4<<<big, kSelTile, 0, st>>>(kbits, kidx, bbits, bidx, bsamples);
         switch (big * kSelBigSamples / kWave) {
         case 4: SOTS_SEL(4, kSelBigTile, kSelBigQuantum, 4, bbits, bidx, bsamples, big); break;
-        case 8: SOTS_SEL(8, kSelBigTile, kSelBigQuantum, 4, bbits, bidx, bsamples, big); break;
         default: return hipErrorInvalidValue;
         }
     }

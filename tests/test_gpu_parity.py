@@ -390,7 +390,7 @@ def test_select_places_exactly_the_rows_recombination_reads(pkg, O, parents, off
     perm = O.sort_perm(f)
     assert np.array_equal(gf[:S], f[perm][:S], equal_nan=True)
     assert np.array_equal(gv[:S], v[perm][:S]) and np.array_equal(gs[:S], s[perm][:S])
-    if 8192 < P <= 262144:    # 16 to 256 tiles of 1024 keys; outside that the population is sorted in full
+    if 8192 < P <= 131072:    # 16 to 128 tiles of 1024 keys; outside that the population is sorted in full
         assert np.all(gf[S:] == -7.0) and np.all(gv[S:] == -7.0) and np.all(gs[S:] == -7.0), "rows beyond S were written"
     # the rest of the order on demand, from the untouched unsorted half
     es.set_sort_mode(pkg.capi.SORT_LAZY_TAIL)
