@@ -204,7 +204,10 @@ __device__ __forceinline__ float4 nt_load4(const float4 *p)
 // mul/add/mul outside the recurrences.  Every per-sample operation is the reference's, in
 // its order, unfused, so the audio is bit-identical to the serial loop.
 // ------------------------------------------------------------------------------------
-constexpr int kSynthUnroll = 8; // samples per pipeline block
+#ifndef SOTS_SYNTH_UNROLL
+#define SOTS_SYNTH_UNROLL 8
+#endif
+constexpr int kSynthUnroll = SOTS_SYNTH_UNROLL; // samples per pipeline block
 #ifndef SOTS_SYNTH_UNROLL_CUT
 #define SOTS_SYNTH_UNROLL_CUT 16
 #endif
