@@ -169,3 +169,48 @@ def test_group_rejects_immigrants_beyond_the_breeding_rows(pkg, O):
         pkg.HipGroup([0, 0, 0], 36, 80, 176, pkg.capi.SYNTH_2OP, 10, None, PMAX)
     g = pkg.HipGroup([0, 0, 0], 32, 80, 176, pkg.capi.SYNTH_2OP, 10, None, PMAX)  # 64 immigrants: the whole breeding rows
     g.close()
+
+
+# kind, parents, offspring, world, elites, sort mode: k_sort_small (P <= 1024, rows of 25 floats; immigrant and elite ranges
+# overlapping), tile sort + rank scatter, the selection kernels (direct and merged tiles), the two-level full sort
+@pytest.mark.parametrize("kind,parents,offspring,world,elites,full", [
+    (0, 32, 96, 2, 24, False), (2, 64, 192, 3, 16, False), (3, 256, 768, 2, 16, False), (0, 2048, 6144, 4, 16, False),
+    (3, 4096, 12288, 8, 16, False), (2, 4096, 12288, 2, 16, True), (0, 32768, 98304, 8, 16, False), (0, 65536, 196608, 8, 16, False)])
+def test_exchange_inside_the_sort_kernel_equals_the_two_launches(pkg, O, kind, parents, offspring, world, elites, full):
+    """sots_fuse_exchange_next_sort: the generation's sort kernel takes the immigrant rows from the gathered buffer and
+    writes the best rows to the send buffer - the same population and the same packed rows as
+    sots_inject_gathered_device + sots_pack_elites_device after the generation, for every kernel that moves sorted rows."""
+    import torch
+    pmax = {0: PMAX, 2: PMAX + [0.0] * 8, 3: [3520.0, 8.0] * 4}[kind]
+    D = {0: 4, 2: 12, 3: 8}[kind]
+    rank = world - 1 if world > 2 else 0
+    rng = np.random.default_rng(parents + world)
+    gathered = torch.from_numpy(rng.random((world * elites, 2 * D + 1), dtype=np.float32)).cuda()
+    target = O.synth(kind, list(rng.random(D)), [0.0] * D, pmax, 512)
+    pops, packs = [], []
+    for fused in (False, True):
+        es = pkg.HipES(parents, offspring, kind, 9, None, pmax, seed=SEED, workgroup_size=32)
+        es.set_target_audio(target)
+        if full:
+            es.set_sort_mode(pkg.capi.SORT_FULL)
+        es.init_population(0)
+        es.execute_generations(2)
+        sink = torch.full((elites, 2 * D + 1), -3.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if fused:
+            es.fuse_exchange_next_sort(sink.data_ptr(), elites, gathered.data_ptr(), world, rank, elites)
+            es.execute_generations(1)
+        else:
+            es.execute_generations(1)
+            es.inject_gathered_device(gathered.data_ptr(), world, rank, elites)
+            es.pack_elites_device(sink.data_ptr(), elites)
+        es.synchronize()
+        packs.append(sink.cpu().numpy())
+        es.execute_generations(1)  # the immigrants take part in the next recombination
+        pops.append(es.read_population())
+        es.close()
+    assert np.array_equal(packs[0], packs[1], equal_nan=True)
+    for x, y in zip(*pops):
+        assert np.array_equal(x, y, equal_nan=True)
+    # the exchange is used once
+    assert not np.all(packs[1] == -3.0)
