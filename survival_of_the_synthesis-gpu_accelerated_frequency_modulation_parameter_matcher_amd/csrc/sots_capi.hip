@@ -388,8 +388,8 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
 #endif
         ctx->pitch = ctx->N + pad;
     }
-    ctx->pd = PopDims{ctx->P, ctx->D, cfg->num_parents, cfg->workgroup_size, cfg->gid_base,
-                      (uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
+    ctx->pd = make_pop_dims(ctx->P, ctx->D, cfg->num_parents, cfg->workgroup_size, cfg->gid_base, (uint32_t)cfg->seed,
+                            (uint32_t)(cfg->seed >> 32));
     // Evolutionary_Strategy.hpp:611-627
     const float mpi = (float)3.14159265358979323846;
     ctx->mc.alpha = 1.4f;

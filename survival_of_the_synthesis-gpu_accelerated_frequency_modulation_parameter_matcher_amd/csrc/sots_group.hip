@@ -136,7 +136,7 @@ struct JobGate {
     // returns once seq != seen
     void wait_job(uint64_t seen)
     {
-        for (uint32_t spins = 0; spins < 200000; ++spins) { // a few hundred microseconds
+        for (uint32_t spins = 0; spins < 50000; ++spins) { // a millisecond or two: the next call of a generation loop comes within ~0.1 ms
             if (seq.load(std::memory_order_acquire) != seen) return;
             __builtin_ia32_pause();
         }

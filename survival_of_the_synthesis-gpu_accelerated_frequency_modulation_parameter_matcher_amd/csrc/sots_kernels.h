@@ -33,7 +33,23 @@ struct PopDims {
     uint32_t block;        // recombination block (reference WRKGRPSIZE)
     uint32_t gid_base;
     uint32_t seed_lo, seed_hi;
+    // recombine_source's divisions as shifts and masks where the sizes allow (they usually do: blocks of 32, 512 parent blocks)
+    uint32_t block_shift;  // log2(block) when block is a power of two, else kNoPow2
+    uint32_t npb;          // parent blocks: max(1, num_parents / block)
+    uint32_t npb_mask;     // npb - 1 when npb is a power of two, else kNoPow2
 };
+constexpr uint32_t kNoPow2 = 0xFFFFFFFFu;
+inline PopDims make_pop_dims(uint32_t p, uint32_t d, uint32_t num_parents, uint32_t block, uint32_t gid_base, uint32_t seed_lo,
+                             uint32_t seed_hi)
+{
+    PopDims pd{p, d, num_parents, block, gid_base, seed_lo, seed_hi, kNoPow2, 1u, kNoPow2};
+    if (block && (block & (block - 1u)) == 0u)
+        for (uint32_t sh = 0; sh < 32; ++sh)
+            if ((1u << sh) == block) pd.block_shift = sh;
+    pd.npb = block && num_parents / block ? num_parents / block : 1u;
+    if ((pd.npb & (pd.npb - 1u)) == 0u) pd.npb_mask = pd.npb - 1u;
+    return pd;
+}
 
 // Variation folded into the synthesis kernel (fused generation loop): when vin != nullptr every
 // lane first builds its individual - recombination source rows of the current half, mutation -

@@ -42,8 +42,11 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64-bit multiply per product (v_mad_u64_u32) instead of a high and a low one: integer multiplies
+        // run at a quarter of the vector rate and are most of what a gene costs
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -91,12 +94,18 @@ __global__ __launch_bounds__(256) void k_init_population(float *__restrict__ val
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t recombine_source(uint32_t i, uint32_t g, const PopDims &pd)
 {
-    const uint32_t b = i / pd.block, dl = i - b * pd.block;
-    uint32_t npb = pd.num_parents / pd.block;
-    npb = npb ? npb : 1u;
-    const uint32_t pb = b % npb;
-    const uint32_t shift = (uint32_t)(((uint64_t)g * (b + 1u)) % pd.block);
-    const uint32_t l = (dl + pd.block - shift) % pd.block;
+    // (g < 16 and b + 1 <= 2^26, so g (b + 1) fits 32 bits; the branches are uniform: pd is a kernel argument)
+    uint32_t b, l;
+    if (pd.block_shift != kNoPow2) {
+        const uint32_t mask = pd.block - 1u;
+        b = i >> pd.block_shift;
+        l = ((i & mask) - g * (b + 1u)) & mask;
+    } else {
+        b = i / pd.block;
+        const uint32_t dl = i - b * pd.block, shift = (g * (b + 1u)) % pd.block;
+        l = (dl + pd.block - shift) % pd.block;
+    }
+    const uint32_t pb = pd.npb_mask != kNoPow2 ? (b & pd.npb_mask) : b % pd.npb;
     return (pb * pd.block + l) * pd.d + g;
 }
 
@@ -302,6 +311,11 @@ struct StampScope {
             g_stamps[2 * 8192 + blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime() - phase_t0_;                 \
     } while (0)
 // absolute clock of any one lane (diagnostics of wavefront start skew inside a workgroup)
+// the chip-wide 100 MHz clock of one lane (when workgroups start and end relative to each other)
+#define SOTS_PHASE_REAL(n)                                                                                         \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 512) g_stamps[2 * 8192 + blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #define SOTS_PHASE_ABS(n, cond)                                                                                   \
     do {                                                                                                           \
         if ((cond) && blockIdx.x < 512) g_stamps[2 * 8192 + blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime(); \
@@ -310,6 +324,7 @@ struct StampScope {
 #define SOTS_STAMP_SCOPE(slot)
 #define SOTS_PHASE_BEGIN()
 #define SOTS_PHASE(n)
+#define SOTS_PHASE_REAL(n)
 #define SOTS_PHASE_ABS(n, cond)
 #endif
 
@@ -388,6 +403,8 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
     constexpr int STAGES = Plan::STAGES;
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
+    SOTS_PHASE_BEGIN();
+    SOTS_PHASE_REAL(10);
     request_wavetable(tab, wavetable);
     bool table_pending = true; // the first tile's parameters are fetched while the table is on its way
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
@@ -417,6 +434,7 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
             }
         }
         __syncthreads();
+        SOTS_PHASE(12); // the individuals are made
         if (wave_id >= STAGES * pairs) { // (a cut kernel keeps a wavefront per stage)
             __builtin_amdgcn_s_waitcnt(0); // this wavefront's pieces of the table have landed before it leaves
             return;
@@ -513,6 +531,7 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
         if (table_pending) {
             wavetable_ready();
             table_pending = false;
+            SOTS_PHASE(13); // the table is in LDS
         }
         SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave_id);
 
@@ -722,8 +741,10 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
         };
         if (free_unclamped) run_my_stage(std::true_type{});
         else run_my_stage(std::false_type{});
+        SOTS_PHASE(14); // the tile's samples are stored (issued)
     }
     if (table_pending) wavetable_ready(); // a workgroup without a tile must not end with copies in flight
+    SOTS_PHASE_REAL(11);
 }
 
 // ------------------------------------------------------------------------------------
