@@ -2541,6 +2541,8 @@ static uint32_t resident_grid(K kernel, int threads, uint32_t items, uint32_t nu
         *cache = per_cu;
     }
     const uint64_t cap = (uint64_t)(num_cus ? num_cus : 256) * (uint64_t)*cache;
+    // (a grid balanced to equal row counts - 2979 workgroups of 22 rows instead of 3072 of 21 or 22 at P = 65536 - measures
+    // the same: profiles/r03_experiments.md)
     return (uint32_t)(items < cap ? items : cap);
 }
 
