@@ -2485,9 +2485,14 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         const uint32_t ht = 4 * waves * kWave;
         switch (kind) {
         case SOTS_SYNTH_2OP: k_synth<SOTS_SYNTH_2OP, 1, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); return hipGetLastError();
-        case SOTS_SYNTH_3OP_SERIES: k_synth<SOTS_SYNTH_3OP_SERIES, 2, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); return hipGetLastError();
+        // up to 64 individuals per CU every operator of a 3- or 4-operator chain gets a wavefront of its own (three or four
+        // SIMDs busy; a stage is one operator long: 3-op N = 2048 P = 1024 105 -> 81 us per generation, 4-op N = 4096 204 -> 170)
+        case SOTS_SYNTH_3OP_SERIES:
+            if (waves == 1) k_synth<SOTS_SYNTH_3OP_SERIES, 1, true, 2><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+            else k_synth<SOTS_SYNTH_3OP_SERIES, 2, true><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+            return hipGetLastError();
         case SOTS_SYNTH_4OP_SERIES:
-            if (waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 2, true, 3><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+            if (waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 1, true, 2, 3><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
             else k_synth<SOTS_SYNTH_4OP_SERIES, 1, true, 2, 3><<<grid, ht, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); // (all eight wavefronts stay)
             return hipGetLastError();
         default: break;
@@ -2500,15 +2505,20 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         break;
     switch (kind) {
         SOTS_SYNTH_CASE(SOTS_SYNTH_2OP, 1)
-        SOTS_SYNTH_CASE(SOTS_SYNTH_3OP_SERIES, 2)
+    case SOTS_SYNTH_3OP_SERIES:
+        // one group of 64 per CU: a wavefront per operator (three SIMDs); two groups: the chain cut once (four wavefronts)
+        if (cut && waves == 1) k_synth<SOTS_SYNTH_3OP_SERIES, 1, false, 2><<<grid, 3 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        else if (cut) k_synth<SOTS_SYNTH_3OP_SERIES, 2><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        else k_synth<SOTS_SYNTH_3OP_SERIES, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        break;
     case SOTS_SYNTH_4OP_SERIES:
-        // up to 64 individuals per CU cut twice - operators {0, 1} | {2} | {3}, three wavefronts on three SIMDs (190 against
-        // 215 us at P = 16384, N = 4096); with two groups per CU six wavefronts would share four SIMDs (279 against 258)
-        if (cut && waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 2, false, 3><<<grid, 3 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        // up to 128 individuals per CU a wavefront per operator: four wavefronts for one group of 64 (round 2: three stages
+        // {0, 1} | {2} | {3} with 16-sample blocks: 165 against 131 us at P = 1024, N = 4096), eight for two (BASELINE configs[3]'s
+        // shard; `-DSOTS_SYNTH_NO_CUT3`: the single cut of round 2 there)
 #ifndef SOTS_SYNTH_NO_CUT3
-        // 65 ... 128 individuals per CU: a wavefront per operator, eight per CU, two per SIMD (BASELINE configs[3]'s shard)
-        else if (cut) k_synth<SOTS_SYNTH_4OP_SERIES, 1, false, 2, 3><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        if (cut) k_synth<SOTS_SYNTH_4OP_SERIES, 1, false, 2, 3><<<grid, 4 * waves * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
 #else
+        if (cut && waves == 1) k_synth<SOTS_SYNTH_4OP_SERIES, 1, false, 2, 3><<<grid, 4 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
         else if (cut) k_synth<SOTS_SYNTH_4OP_SERIES, 2><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
 #endif
         else k_synth<SOTS_SYNTH_4OP_SERIES, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
