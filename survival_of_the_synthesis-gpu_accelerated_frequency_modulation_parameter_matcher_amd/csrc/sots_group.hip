@@ -124,7 +124,6 @@ struct sots_group {
     JobGate gate;
     SpinBarrier *barrier = nullptr;
     std::vector<int> rcs;    // per island, result of the current job
-    int pending_out = -1;    // island 0's view of `pending` at the end of the job
 };
 
 namespace {
