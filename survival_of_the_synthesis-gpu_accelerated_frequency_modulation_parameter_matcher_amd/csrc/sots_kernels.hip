@@ -789,7 +789,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); } // a * (-i)
 
 // ---- complex values as 2-vectors (register pairs): v_pk_add/mul/fma_f32 do a complex add, or half a complex
 // multiply, per instruction, and every wave64 vector instruction holds the SIMD for 4 cycles whatever it does
@@ -830,6 +829,41 @@ __device__ __forceinline__ v2f_t xc_sub_conj(v2f_t a, v2f_t b)
 }
 
 
+// a * e^{-i pi/4} and a * e^{-3 i pi/4} for a = (x, y): ((x + y) s, (y - x) s) and ((y - x) s, -(x + y) s), s = sqrt(1/2) -
+// one packed add with swapped and negated halves and one packed multiply each (the same sums and products as the scalar
+// form, so the same bits)
+__device__ __forceinline__ float2 rot_m45(float2 a)
+{
+    const v2f_t av = xv(a);
+    v2f_t t;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(av)); // (x + y, y - x)
+    t = t * v2f_t{0.70710678118654752440f, 0.70710678118654752440f};
+    return make_float2(t.x, t.y);
+}
+__device__ __forceinline__ float2 rot_m135(float2 a)
+{
+    const v2f_t av = xv(a);
+    v2f_t t;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(t) : "v"(av)); // (y - x, -x - y)
+    t = t * v2f_t{0.70710678118654752440f, 0.70710678118654752440f};
+    return make_float2(t.x, t.y);
+}
+
+// a + (-i) d = (a.x + d.y, a.y - d.x) and a - (-i) d = (a.x - d.y, a.y + d.x) in ONE packed add each (half selects and negations
+// are instruction modifiers): a butterfly's rotation by -i never becomes a register shuffle
+__device__ __forceinline__ float2 add_negi(float2 a, float2 d)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(xv(a)), "v"(xv(d)));
+    return make_float2(r.x, r.y);
+}
+__device__ __forceinline__ float2 sub_negi(float2 a, float2 d)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(xv(a)), "v"(xv(d)));
+    return make_float2(r.x, r.y);
+}
+
 template <int R> struct Dft;
 template <> struct Dft<2> {
     static __device__ __forceinline__ void run(float2 *v)
@@ -843,11 +877,11 @@ template <> struct Dft<4> {
     static __device__ __forceinline__ void run(float2 *v)
     {
         const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-        const float2 t2 = cadd(v[1], v[3]), t3 = mul_neg_i(csub(v[1], v[3]));
+        const float2 t2 = cadd(v[1], v[3]), d = csub(v[1], v[3]);
         v[0] = cadd(t0, t2);
-        v[1] = cadd(t1, t3);
+        v[1] = add_negi(t1, d); // t1 + (-i) d
         v[2] = csub(t0, t2);
-        v[3] = csub(t1, t3);
+        v[3] = sub_negi(t1, d);
     }
 };
 template <> struct Dft<8> {
@@ -857,15 +891,13 @@ template <> struct Dft<8> {
         float2 o[4] = {v[1], v[3], v[5], v[7]};
         Dft<4>::run(e);
         Dft<4>::run(o);
-        const float s = 0.70710678118654752440f;
-        // o[k] *= exp(-2 pi i k / 8)
-        o[1] = make_float2((o[1].x + o[1].y) * s, (o[1].y - o[1].x) * s);
-        o[2] = mul_neg_i(o[2]);
-        o[3] = make_float2((o[3].y - o[3].x) * s, -(o[3].x + o[3].y) * s);
+        // o[k] *= exp(-2 pi i k / 8); k = 2 (a rotation by -i) folded into its butterfly
+        o[1] = rot_m45(o[1]);
+        o[3] = rot_m135(o[3]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[k] = cadd(e[k], o[k]);
-            v[k + 4] = csub(e[k], o[k]);
+            v[k] = k == 2 ? add_negi(e[k], o[k]) : cadd(e[k], o[k]);
+            v[k + 4] = k == 2 ? sub_negi(e[k], o[k]) : csub(e[k], o[k]);
         }
     }
 };
@@ -1059,6 +1091,16 @@ __device__ __forceinline__ float bin_error(float2 x, float target, float scale)
     return e * e;
 }
 
+// Two bins at once, each with its own running sum: the magnitudes come out of v_sqrt_f32 one by one, the scale, the
+// subtraction and the squared accumulation are packed (acc2 = (sum over the bins k, sum over the bins M - k); k_fft<., 1> and
+// k_fitness add the two halves in the same order, so both paths still give the same fp32 sum)
+__device__ __forceinline__ void bin_error2(v2f_t &acc2, float2 xa, float2 xb, float ta, float tb, float scale)
+{
+    const v2f_t raw = v2f_t{__builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y), __builtin_amdgcn_sqrtf(xb.x * xb.x + xb.y * xb.y)};
+    const v2f_t e = raw * v2f_t{scale, scale} - v2f_t{ta, tb};
+    acc2 = acc2 + e * e;
+}
+
 // Wavefront sum without LDS traffic: DPP swaps inside each row of 16 lanes (every lane of a
 // row ends with the row total), then the four row totals are added in row order.
 template <int CTRL>
@@ -1127,7 +1169,11 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     // transformed - a row's transform is shorter than the loaded memory latency, and the registers
     // are there (168 = three wavefronts per SIMD).
     auto request = [&](float4 (&dst)[Q], uint32_t r) { // rows past the end re-read the last valid one
+#ifdef SOTS_ABL_FFT_CACHED_ROWS
+        const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)((r < p_len ? r : ind) & 511u) * pitch); // timing ablation: rows from L2
+#else
         const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)(r < p_len ? r : ind) * pitch);
+#endif
 #pragma unroll
         for (int h = 0; h < Q; ++h) dst[h] = SOTS_ROW_LOAD(in + lane + kWave * h);
     };
@@ -1148,8 +1194,10 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
         SOTS_FFT_T(t1);
         if constexpr (WIN) {
 #pragma unroll
-            for (int h = 0; h < Q; ++h)
-                cur[h] = make_float4(cur[h].x * wv[h].x, cur[h].y * wv[h].y, cur[h].z * wv[h].z, cur[h].w * wv[h].w);
+            for (int h = 0; h < Q; ++h) { // two packed multiplies per 16 bytes
+                const v2f_t lo = v2f_t{cur[h].x, cur[h].y} * v2f_t{wv[h].x, wv[h].y}, hi = v2f_t{cur[h].z, cur[h].w} * v2f_t{wv[h].z, wv[h].w};
+                cur[h] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
         }
         request(fill, ind + 2 * gridDim.x);
         float2 z[E]; // z[s] = Z[lane + 64 s]
@@ -1169,17 +1217,16 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
             }
             if (lane == 0) row[M / 2] = x_half;
         } else {
-            float acc = 0.0f;
+            v2f_t acc2 = v2f_t{0.0f, 0.0f};
 #pragma unroll
             for (int q = 0; q < H; ++q) {
                 const int k = lane + kWave * q;
                 v2f_t xa2, xbc2;
                 split_pair_2x(z[q], split_partner<M>(z, q, lane, partner_addr), w_split[q], xa2, xbc2); // 2 X[k], 2 conj X[M-k]
                 if (k == 0) xbc2 = v2f_t{2.0f * x_half.x, 2.0f * x_half.y}; // the fitness skips the Nyquist bin and needs bin M/2
-                acc += bin_error(make_float2(xa2.x, xa2.y), tgt_s[k], half_scale);
-                acc += bin_error(make_float2(xbc2.x, xbc2.y), tgt_s[k == 0 ? M / 2 : M - k], half_scale);
+                bin_error2(acc2, make_float2(xa2.x, xa2.y), make_float2(xbc2.x, xbc2.y), tgt_s[k], tgt_s[k == 0 ? M / 2 : M - k], half_scale);
             }
-            acc = wave_sum(acc);
+            float acc = wave_sum(acc2.x + acc2.y);
             if (lane == 0) fitness[ind] = acc;
         }
         ind += gridDim.x;
@@ -1225,15 +1272,14 @@ __global__ __launch_bounds__(kWave) void k_fitness(const float *__restrict__ spe
     const int lane = threadIdx.x;
     for (uint32_t ind = blockIdx.x; ind < p_len; ind += gridDim.x) {
         const float2 *__restrict__ row = reinterpret_cast<const float2 *>(spectrum + (size_t)ind * (N + 8));
-        float acc = 0.0f;
+        v2f_t acc2 = v2f_t{0.0f, 0.0f};
 #pragma unroll
         for (int q = 0; q < E / 2; ++q) {
             const int k = lane + kWave * q;
             const int kb = k == 0 ? M / 2 : M - k;
-            acc += bin_error(row[k], target[k], inv_n * inv_wf);
-            acc += bin_error(row[kb], target[kb], inv_n * inv_wf);
+            bin_error2(acc2, row[k], row[kb], target[k], target[kb], inv_n * inv_wf);
         }
-        acc = wave_sum(acc);
+        float acc = wave_sum(acc2.x + acc2.y);
         if (lane == 0) fitness[ind] = acc;
     }
 }
