@@ -390,17 +390,23 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
                                                                uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
 {
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
-    using Plan = CutPlan<SPLIT, SPLIT2, SPLIT3, OPS>;
-    constexpr int U = Plan::U;
-    constexpr int CH = Plan::CH;        // 16-byte chunks per tile row = 4 CH samples per flush
+    // SPLIT < 0 (the voice of J parallel chains, up to 64 individuals per CU): a wavefront per CHAIN.  Every wavefront runs
+    // its chain's operators as the uncut pipeline does; the chains of wavefronts 1 ... J-1 hand gain * (table value) - the
+    // reference's product - to wavefront 0 through LDS, one block per trip and one workgroup barrier per trip as in the
+    // series cuts, and wavefront 0 adds them to its own in the reference's order and owns the tile.
+    constexpr bool PSPLIT = SPLIT < 0;
+    using Plan = CutPlan<(PSPLIT ? 0 : SPLIT), SPLIT2, SPLIT3, OPS>;
+    constexpr int U = PSPLIT ? kSynthUnrollCut : Plan::U;
+    constexpr int CH = PSPLIT ? kStageChunks : Plan::CH; // 16-byte chunks per tile row = 4 CH samples per flush
     constexpr int RPI = kWave / CH;     // rows per transposed read / store instruction (CH of them per flush)
     static_assert(U % 4 == 0 && 4 * CH % U == 0, "whole 16-byte chunks, whole blocks per flush");
-    static_assert(SPLIT == 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
+    static_assert(SPLIT <= 0 || (J == 1 && SPLIT < OPS), "only a series chain can be cut");
+    static_assert(!PSPLIT || (J == 3 && OPS == 2 && !HELP && SPLIT2 == 0), "the parallel split serves the three 2-operator chains");
     static_assert(SPLIT2 == 0 || (SPLIT > 0 && SPLIT2 > SPLIT && SPLIT2 < OPS), "the second cut lies behind the first");
     static_assert(SPLIT3 == 0 || (SPLIT2 > 0 && SPLIT3 > SPLIT2 && SPLIT3 < OPS), "the third cut lies behind the second");
     static_assert(!HELP || SPLIT > 0 || D == 4, "uncut, the helper wavefronts serve the 4-gene voice (128 registers with 16 wavefronts)");
     constexpr uint32_t HT = 4; // HELP: threads per individual while the genes are made (each takes genes t % 4, t % 4 + 4, ...)
-    constexpr int STAGES = Plan::STAGES;
+    constexpr int STAGES = PSPLIT ? J : Plan::STAGES; // wavefronts per 64 individuals
     __shared__ float tab[kWavetableSize];
     __shared__ float4 stage_all[kSynthWaves * kWave * kStageChunks];
     SOTS_PHASE_BEGIN();
@@ -539,6 +545,7 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
             constexpr bool UNCLAMPED = decltype(unclamped_tag)::value;
             constexpr int MY = decltype(stage_tag)::value; // this wavefront's stage, a compile-time fact in here: its loop holds
                                                           // (and keeps registers for) its own operators only
+            constexpr int CHAIN = PSPLIT ? STAGES - 1 - MY : 0; // parallel split: this wavefront's chain (the tail runs chain 0)
             float pos[OPS][J];
 #pragma unroll
             for (int o = 0; o < OPS; ++o)
@@ -547,6 +554,39 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
             float T[OPS][2][J][U]; // table values of operator s, block parity, chain, sample
             v2f_t handed[U / 2];   // cut kernels: the increments fetched for this wavefront's first operator
             v2f_t to_hand[U / 2];  // ... and the ones made for the next stage's
+            v2f_t handed2[PSPLIT ? U / 2 : 1]; // parallel split: handed = chain 1's products, handed2 = chain 2's
+            // parallel split: this chain's products of its block of parity B (table values read one trip ago) ...
+            auto par_make = [&](auto b_tag) {
+                constexpr int B = decltype(b_tag)::value;
+                if constexpr (PSPLIT && CHAIN != 0) {
+#pragma unroll
+                    for (int u = 0; u < U; u += 2)
+                        to_hand[u / 2] = v2f_t{T[OPS - 1][B][CHAIN][u], T[OPS - 1][B][CHAIN][u + 1]} * gain[CHAIN];
+                }
+            };
+            // ... go to the tail through this chain's link (chain 1: xbuf0, chain 2: xbuf1) ...
+            auto par_send = [&](auto b_tag) {
+                constexpr int B = decltype(b_tag)::value;
+                if constexpr (PSPLIT && CHAIN != 0) {
+                    float4 *__restrict__ xout = CHAIN == 1 ? xbuf0 : xbuf1;
+#pragma unroll
+                    for (int u = 0; u < U; u += 4)
+                        xout[(B * (U / 4) + u / 4) * kWave + lane] =
+                            make_float4(to_hand[u / 2].x, to_hand[u / 2].y, to_hand[u / 2 + 1].x, to_hand[u / 2 + 1].y);
+                }
+            };
+            // ... where the tail picks both up one trip later
+            auto par_fetch = [&](auto b_tag) {
+                constexpr int B = decltype(b_tag)::value;
+                if constexpr (PSPLIT && CHAIN == 0) {
+#pragma unroll
+                    for (int u = 0; u < U; u += 4) {
+                        const float4 q1 = xbuf0[(B * (U / 4) + u / 4) * kWave + lane], q2 = xbuf1[(B * (U / 4) + u / 4) * kWave + lane];
+                        handed[u / 2] = v2f_t{q1.x, q1.y}, handed[u / 2 + 1] = v2f_t{q1.z, q1.w};
+                        handed2[u / 2] = v2f_t{q2.x, q2.y}, handed2[u / 2 + 1] = v2f_t{q2.z, q2.w};
+                    }
+                }
+            };
 
             // Schedule (CutPlan): operator S works on block k - slot(S) in trip k.  A block's parity (which half of T,
             // which hand-over buffer) is its index & 1.
@@ -589,9 +629,10 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
             // operator S on its block of parity B
             auto op = [&](auto s_tag, auto b_tag) {
                 constexpr int S = decltype(s_tag)::value, B = decltype(b_tag)::value;
-                if constexpr (Plan::stage_of(S) == MY) // else: another wavefront's operator
+                if constexpr (PSPLIT || Plan::stage_of(S) == MY) // else: another wavefront's operator
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
+                    if (PSPLIT && j != CHAIN) continue; // (compile-time after unrolling: another wavefront's chain)
                     if constexpr (S == 0) {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
@@ -642,7 +683,10 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
                 float y[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if constexpr (KIND == SOTS_SYNTH_TRIPLE_PAR)
+                    if constexpr (PSPLIT) // chains 1 and 2 arrive as products from their wavefronts: the same sum in the same order
+                        y[u] = (T[OPS - 1][B][0][u] * gain[0] + ((u & 1) ? handed[u / 2].y : handed[u / 2].x) +
+                                ((u & 1) ? handed2[u / 2].y : handed2[u / 2].x)) / 3.0f;
+                    else if constexpr (KIND == SOTS_SYNTH_TRIPLE_PAR)
                         y[u] = (T[OPS - 1][B][0][u] * gain[0] + T[OPS - 1][B][1][u] * gain[1] + T[OPS - 1][B][2][u] * gain[2]) /
                                3.0f; // == (float)(double(sum)/3.0), :493
                     else
@@ -683,7 +727,10 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
                 }
             };
             const uint32_t nb = n / U; // even and >= 32
-            constexpr int LAST = Plan::slot(OPS); // the slot in which a block leaves
+            // the slot in which a block leaves; parallel split: one trip later than the uncut pipeline (the other chains' products
+            // are made in slot OPS and read in slot OPS + 1; the tail's own table values of that block live until the operator
+            // of the same parity overwrites them later in the same trip: the samples leave first)
+            constexpr int LAST = PSPLIT ? OPS + 1 : Plan::slot(OPS);
             // Trip k of parity Q.  EDGE (the first and last trips): a slot only works while its block index lies in
             // [0, nb).  Cut kernels: what a wavefront waits for from another stage is asked for first, work that does
             // not need it comes next (the hand-over arithmetic of the block read one trip ago, the samples that leave),
@@ -700,7 +747,17 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
                     if constexpr (OPS > 2) if (on(Plan::slot(2) + SH)) f(ic<2>{}, ic<(Q ^ ((Plan::slot(2) + SH) & 1))>{});
                     if constexpr (OPS > 3) if (on(Plan::slot(3) + SH)) f(ic<3>{}, ic<(Q ^ ((Plan::slot(3) + SH) & 1))>{});
                 };
-                if constexpr (SPLIT > 0) {
+                if constexpr (PSPLIT) {
+                    if (on(LAST)) par_fetch(ic<(Q ^ (LAST & 1))>{});
+                    if (on(OPS)) par_make(ic<(Q ^ (OPS & 1))>{});
+                    if (on(LAST)) emit(ic<(Q ^ (LAST & 1))>{}, (k - LAST) * U);
+                    each_op(op, ic<0>{});
+                    if (on(OPS)) par_send(ic<(Q ^ (OPS & 1))>{});
+                    asm volatile("" ::: "memory");
+                    if constexpr (CHAIN != 0) __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the products are in LDS
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                } else if constexpr (SPLIT > 0) {
                     each_op(fetch, ic<0>{});
                     each_op(make_handover, ic<1>{}); // the block this operator read the table for one trip ago
                     if (on(LAST)) emit(ic<(Q ^ (LAST & 1))>{}, (k - LAST) * U);
@@ -2569,7 +2626,11 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
 #endif
         else k_synth<SOTS_SYNTH_4OP_SERIES, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
         break;
-    case SOTS_SYNTH_TRIPLE_PAR: k_synth<SOTS_SYNTH_TRIPLE_PAR, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var); break;
+    case SOTS_SYNTH_TRIPLE_PAR:
+        // up to 64 individuals per CU a wavefront per chain (three SIMDs): 134 -> ... us at P = 1024 (profiles/r03_experiments.md)
+        if (allow_cut && waves == 1) k_synth<SOTS_SYNTH_TRIPLE_PAR, -1><<<grid, 3 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        else k_synth<SOTS_SYNTH_TRIPLE_PAR, 0><<<grid, threads, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        break;
     default: return hipErrorInvalidValue;
     }
 #undef SOTS_SYNTH_CASE

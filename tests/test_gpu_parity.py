@@ -609,6 +609,28 @@ def test_synthesise_four_op_one_wavefront_per_operator_bitexact(pkg, O, parents,
     es.close()
 
 
+@pytest.mark.parametrize("parents,offspring,log2n", [(1024, 3072, 10), (4096 - 32, 12288, 9), (16, 16, 11)])
+def test_synthesise_triple_voice_one_wavefront_per_chain_bitexact(pkg, O, parents, offspring, log2n):
+    """Up to 64 individuals per CU the voice of three parallel 2-operator chains runs a wavefront per chain
+    (k_synth<TRIPLE, -1>): chains 1 and 2 hand their gain * table products to the wavefront of chain 0, which adds them in
+    the reference's order (Evolutionary_Strategy.hpp:493).  Spot rows bit for bit against the oracle, partly filled tiles
+    included."""
+    kind = 2
+    es, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    es.init_population(0)
+    v, s, _ = es.read_population()
+    _, tv = target_audio(O, kind, es.N)
+    v[0], v[1], v[2] = tv, 0.0, 1.0
+    es.write_population(v, s, None)
+    es.synthesise()
+    audio = es.read_audio()
+    rng = np.random.default_rng(29)
+    rows = np.unique(np.concatenate([[0, 1, 2, min(63, es.P - 1), es.P - 1], rng.choice(es.P, min(es.P, 80), replace=False)]))
+    for r in rows:
+        assert np.array_equal(audio[r], O.synth(kind, v[r], [0.0] * 4, PMAX[kind], es.N)), f"row {r}"
+    es.close()
+
+
 def test_full_size_properties_config2(pkg, O):
     """BASELINE configs[2]: P = 65536 (16384 + 49152), 2-op, N = 1024, one GPU."""
     full_size_properties(pkg, O, 16384, 49152, 0, 10)
