@@ -1792,15 +1792,15 @@ __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict_
 
 // A whole population of at most 1024 rows in ONE launch and one workgroup (the reference's default sizes are this
 // small, and there a launch costs as much as the sort): k_sel_tiles' network - one key per lane, 64-key runs sorted in
-// registers, a key's place = its lane + its lower bounds in the other runs - and then every lane moves the row whose
-// key it ended up with.  Same order as the full sort: fitness, equal fitness by index, NaN last.
+// registers, a key's place = its lane + its lower bounds in the other runs - and then the workgroup moves the rows,
+// a lane per output element.  Same order as the full sort: fitness, equal fitness by index, NaN last.
 template <uint32_t RUNS>
 __global__ __launch_bounds__(RUNS *kWave) void k_sort_small(const float *__restrict__ vin, const float *__restrict__ sin,
                                                             const float *__restrict__ fin, float *__restrict__ vout,
                                                             float *__restrict__ sout, float *__restrict__ fout,
                                                             uint32_t p_len, uint32_t d, uint32_t first_row, SortExchange ex)
 {
-    __shared__ uint32_t runs[RUNS * kWave];
+    __shared__ uint32_t runs[RUNS * kWave], from[RUNS * kWave];
     ex_unpack(ex, vout, sout, fout, d, threadIdx.x, RUNS * kWave);
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -1811,16 +1811,6 @@ __global__ __launch_bounds__(RUNS *kWave) void k_sort_small(const float *__restr
     bitonic_merge<16, 8>(b, i, lane);
     bitonic_merge<32, 16>(b, i, lane);
     bitonic_merge<64, 32>(b, i, lane);
-    // this lane now holds row i's key and moves that row: its first genes are asked for before its place is known
-    const bool real = i < p_len;
-    const uint32_t src = real ? i : 0u;
-    float v4[4], s4[4];
-#pragma unroll
-    for (uint32_t c = 0; c < 4; ++c) {
-        v4[c] = c < d ? vin[src * d + c] : 0.0f;
-        s4[c] = c < d ? sin[src * d + c] : 0.0f;
-    }
-    const float f = fin[src];
     uint32_t rank = lane;
     if constexpr (RUNS > 1) {
         runs[tid] = b;
@@ -1839,27 +1829,41 @@ __global__ __launch_bounds__(RUNS *kWave) void k_sort_small(const float *__restr
 #pragma unroll
         for (uint32_t w = 0; w < RUNS; ++w) rank += pos[w] - w * kWave + (runs[pos[w]] < thr[w] ? 1u : 0u);
     }
-    if (!real || rank < first_row) return; // padding keys sort behind every row
-    if (ex_immigrant_row(ex, rank)) return; // an immigrant's place
-    fout[rank] = f;
-    ex_sink(ex, rank, 2 * d, d, f);
+    // from[place] = the row that sorted there (padding keys sort behind every row).  The rows then move with lane =
+    // OUTPUT element: a wavefront's stores are consecutive addresses and its loads runs of d consecutive floats - one
+    // workgroup is one CU's address path, and a lane-per-row move (64 cache lines per instruction, 2 d + 1
+    // instructions each way) took twice as long as the sort itself at d = 12.
+    from[rank] = i;
+    __syncthreads();
+    constexpr uint32_t T = RUNS * kWave;
+    if (tid < p_len && tid >= first_row && !ex_immigrant_row(ex, tid)) {
+        const float f = fin[from[tid]];
+        fout[tid] = f;
+        ex_sink(ex, tid, 2 * d, d, f);
+    }
+    const uint32_t qd = T / d, rd = T - qd * d; // uniform: one scalar division per launch
+    uint32_t r = tid / d, c = tid - r * d;
+    while (r < p_len) { // four elements per trip, their loads in flight together
+        uint32_t dst[4], row[4];
+        float v[4], s[4];
+        bool ok[4];
 #pragma unroll
-    for (uint32_t c = 0; c < 4; ++c)
-        if (c < d) {
-            vout[rank * d + c] = v4[c], sout[rank * d + c] = s4[c];
-            ex_sink(ex, rank, c, d, v4[c]), ex_sink(ex, rank, d + c, d, s4[c]);
+        for (uint32_t q = 0; q < 4; ++q) {
+            row[q] = r, dst[q] = r * d + c;
+            ok[q] = r < p_len && r >= first_row && !ex_immigrant_row(ex, r);
+            if (ok[q]) {
+                const uint32_t src = from[r] * d + c;
+                v[q] = vin[src], s[q] = sin[src];
+            }
+            r += qd, c += rd;
+            if (c >= d) c -= d, ++r;
         }
-    for (uint32_t c0 = 4; c0 < d; c0 += 4) { // wider voices: four more genes per trip
 #pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) {
-            v4[c] = c0 + c < d ? vin[src * d + c0 + c] : 0.0f;
-            s4[c] = c0 + c < d ? sin[src * d + c0 + c] : 0.0f;
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c)
-            if (c0 + c < d) {
-                vout[rank * d + c0 + c] = v4[c], sout[rank * d + c0 + c] = s4[c];
-                ex_sink(ex, rank, c0 + c, d, v4[c]), ex_sink(ex, rank, d + c0 + c, d, s4[c]);
+        for (uint32_t q = 0; q < 4; ++q)
+            if (ok[q]) {
+                const uint32_t cq = dst[q] - row[q] * d;
+                vout[dst[q]] = v[q], sout[dst[q]] = s[q];
+                ex_sink(ex, row[q], cq, d, v[q]), ex_sink(ex, row[q], d + cq, d, s[q]);
             }
     }
 }
