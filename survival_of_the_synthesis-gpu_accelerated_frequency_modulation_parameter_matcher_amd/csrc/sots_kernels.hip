@@ -2318,8 +2318,14 @@ __global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(cons
     constexpr int S2 = E + 2, S1 = E + 4; // lane strides of the float2 / float tables (16-byte reads, spread over the banks)
     __shared__ __attribute__((aligned(16))) float2 tw2_s[kWave * S2], tws_s[kWave * S2], win_s[WIN ? kWave * S2 : 1];
     __shared__ __attribute__((aligned(16))) float tgt_s[MODE == 1 ? kWave * S1 : 4];
+    __shared__ uint32_t next_s; // the workgroup's rows are dealt out as its wavefronts ask for them (below)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (tid == 0) next_s = W;
+#ifdef SOTS_STAMP
+    const unsigned long long xs_begin = __builtin_amdgcn_s_memrealtime(), xs_begin_clk = __builtin_amdgcn_s_memtime();
+    unsigned long long xs_wait = 0, xs_rows = 0, xs_split = 0;
+#endif
     for (uint32_t e = tid; e < kWave * E; e += W * kWave) {
         const uint32_t l = e / E, r = e % E;
         const uint32_t q = __brev(r) >> (32 - EB), pp = __brev(l) >> 26, k = q + E * pp;
@@ -2341,9 +2347,16 @@ __global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(cons
     const float half_scale = 0.5f * (inv_n * inv_wf);
     __syncthreads();
 
-    // rows: wavefront w of workgroup b takes b W + w, then every (grid W)-th
+    // Rows: workgroup b owns rows b W + w + i grid W (w < W, i = 0, 1, ...).  Its wavefronts start with i = 0, wavefront w
+    // on row b W + w, and then take the workgroup's remaining rows in that order AS THEY FINISH: the SIMD issues for its
+    // oldest wavefront first, so with a fixed deal of 8 rows each the wavefronts of one launch end anywhere between 77
+    // and 148 us (N = 4096, P = 32768) and the last ones run alone, far below the issue rate (tools/fftx_probe.py).
+    // Which wavefront transforms a row changes nothing in its result.
     uint32_t row = blockIdx.x * W + wave;
     if (row >= p_len) return;
+#ifdef SOTS_STAMP
+    const unsigned long long xs_tables = __builtin_amdgcn_s_memrealtime();
+#endif
     v2f_t x[E];
     {
         const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)row * pitch);
@@ -2351,9 +2364,19 @@ __global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(cons
         for (int j = 0; j < E; ++j) x[j] = x_row_load(in + lane + kWave * j);
     }
     while (true) {
-        const uint32_t nxt = row + gridDim.x * W;
-        const bool more = nxt < p_len;
+        uint32_t take = 0;
+        if (lane == 0) take = atomicAdd(&next_s, 1u); // (answered long before the split below needs it)
+        take = __builtin_amdgcn_readfirstlane(take);
+        const uint32_t nxt = blockIdx.x * W + take % W + (take / W) * gridDim.x * W;
+        const bool more = nxt < p_len; // (rows past the end: every later take is past it too)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef SOTS_STAMP
+        {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            xs_wait += __builtin_amdgcn_s_memtime() - t0, xs_rows += 1;
+        }
+#endif
         if constexpr (WIN) {
 #pragma unroll
             for (int j = 0; j < E; j += 2) {
@@ -2389,6 +2412,9 @@ __global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(cons
         x_lane_stage<1>(x, sg1, one);
         __builtin_amdgcn_sched_barrier(0);
         // split: this lane's E bins k = bitrev(r) + E p
+#ifdef SOTS_STAMP
+        const unsigned long long xs_t2 = __builtin_amdgcn_s_memtime();
+#endif
         float acc = 0.0f;
         v2f_t out_even = v2f_t{0.f, 0.f}; // MODE 0: bins leave two at a time, in bin order
         float2 *__restrict__ dst = MODE == 0 ? reinterpret_cast<float2 *>(spectrum + (size_t)row * (N + 8)) + E * pp : nullptr;
@@ -2419,10 +2445,10 @@ __global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(cons
                         const v2f_t xb = bin2x(ic<R2>{});
                         acc += bin_error(make_float2(xb.x, xb.y), tgt_s[lane * S1 + R2], half_scale);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
 #ifndef SOTS_X_RECYCLE
 #define SOTS_X_RECYCLE 1
 #endif
+                    __builtin_amdgcn_sched_barrier(0);
                     if constexpr (SOTS_X_RECYCLE != 0) {
                         x[RR] = x_row_load(in_next + lane + kWave * RR);
                         if constexpr (R2 != RR) x[R2] = x_row_load(in_next + lane + kWave * R2);
@@ -2457,6 +2483,14 @@ __global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(cons
             acc = wave_sum(acc);
             if (lane == 0) fitness[row] = acc;
         }
+#ifdef SOTS_STAMP
+        xs_split += __builtin_amdgcn_s_memtime() - xs_t2;
+        if (lane == 0 && blockIdx.x * W + wave < 2048) { // per wavefront: 8 words
+            unsigned long long *o = g_stamps + (blockIdx.x * W + wave) * 8;
+            o[0] = xs_begin, o[1] = xs_tables, o[2] = __builtin_amdgcn_s_memrealtime(), o[3] = xs_rows;
+            o[4] = xs_wait, o[5] = xs_split, o[6] = __builtin_amdgcn_s_memtime() - xs_begin_clk;
+        }
+#endif
         if (!more) break;
         if constexpr (MODE == 0 || SOTS_X_RECYCLE == 0) { // (MODE 1 has asked for the row already, pair by pair)
             const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)nxt * pitch);
