@@ -69,6 +69,7 @@ struct Variation {
 struct OccCache {
     int fft[16], fitness[16], fused_win[16], fused_raw[16];
     int x_fft[16], x_fitness[16], x_fused_win[16], x_fused_raw[16];
+    int wide[4]; // k_fft with twelve wavefronts per workgroup: spectrum writer, fused with / without window
 };
 
 // ---- variation ----

@@ -1072,15 +1072,24 @@ __device__ __forceinline__ void preload_twiddles(float2 (&twr)[tw_count<M>()], c
     }
 }
 
-template <int M>
+// Between the passes of ONE wavefront's transform.  A workgroup of one wavefront: __syncthreads(), of which the compiler
+// drops the s_barrier and keeps the fence (s_waitcnt lgkmcnt(0)).  A workgroup of several wavefronts, each with its own
+// piece of LDS (W > 1 below): the fence written out - a barrier would tie the wavefronts together for nothing.  (The LDS
+// executes a wavefront's instructions in order; ordering them by a compiler barrier alone measures the same,
+// profiles/r03_experiments.md.)
+template <bool ALONE>
+__device__ __forceinline__ void wave_lds_sync()
+{
+    if constexpr (ALONE) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int M, bool ALONE = true>
 __device__ __forceinline__ void fft_forward(const float4 (&q)[M / kWave / 2], float2 *__restrict__ lds,
                                             const float2 *__restrict__ tw, const float2 (&twr)[tw_count<M>()], int lane,
                                             float2 (&x)[M / kWave])
 {
-// (the workgroup is one wavefront: the compiler drops the s_barrier and keeps the fence, s_waitcnt lgkmcnt(0); ordering
-// the LDS accesses by a compiler barrier alone - the LDS executes a wavefront's instructions in order - measures the same,
-// profiles/r03_experiments.md)
-#define SOTS_SYNC() __syncthreads()
+#define SOTS_SYNC() wave_lds_sync<ALONE>()
 #define SOTS_FIRST(R)                        \
     fft_first_pass<M, R>(q, lds, lane);      \
     SOTS_SYNC();
@@ -1184,20 +1193,32 @@ __device__ __forceinline__ float wave_sum(float v)
 // WIN: multiply by the fp32 window while loading (the generation loop then skips the window
 // pass; the product is the same single fp32 rounding either way).
 // Rows of N <= 1024 only (longer rows: k_fft_x).
-template <int LOG2N, int MODE, bool WIN>
-__global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
-                                               const float *__restrict__ target, float *__restrict__ fitness,
-                                               const float2 *__restrict__ tw, const float *__restrict__ window,
-                                               uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
+// W: wavefronts per workgroup, each transforming rows of its own.  W = 1: workgroup b takes rows b, b + grid, ... - small
+// populations, a wavefront wherever there is room.  W = 12 (N = 1024: what the registers let a CU hold, ONE workgroup per
+// CU): the workgroup's rows b + t grid are dealt to its wavefronts as they ask (an LDS counter).  The SIMD issues for its
+// oldest wavefront first: with a fixed deal the three wavefronts of a SIMD finish their equal shares one after the
+// other and the last one runs alone, far below the issue rate (k_fft_x below has the numbers).
+template <int LOG2N> constexpr int fft_wide_waves() { return LOG2N == 10 ? 12 : 16; }
+template <int LOG2N, int MODE, bool WIN, int W = 1>
+__global__ __launch_bounds__(W *kWave) void k_fft(const float *__restrict__ audio, float *__restrict__ spectrum,
+                                                   const float *__restrict__ target, float *__restrict__ fitness,
+                                                   const float2 *__restrict__ tw, const float *__restrict__ window,
+                                                   uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, E = M / kWave, H = E / 2;
     static_assert(LOG2N == 9 || LOG2N == 10, "wavefront-per-row FFT is for N <= 1024");
-    __shared__ float2 lds[M + M / 8 + 1];
-    const int lane = threadIdx.x;
+    __shared__ float2 lds_all[W][M + M / 8 + 1];
+    __shared__ uint32_t next_s;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    float2 *const lds = lds_all[wave];
     const float half_scale = 0.5f * (inv_n * inv_wf); // the split below leaves a factor of two in
     const int partner_addr = ((kWave - lane) & (kWave - 1)) * 4; // ds_bpermute byte address of lane 64-l
-    uint32_t ind = blockIdx.x;
-    if (ind >= p_len) return;
+    // buffer b0 starts with take `wave`, b1 with take W + wave; take t is row blockIdx.x + t grid
+    const uint32_t grid = gridDim.x;
+    uint32_t ind = blockIdx.x + wave * grid;
+    if (W == 1 && ind >= p_len) return;
+    if (threadIdx.x == 0) next_s = 2 * W;
 
     // per-lane constants of the split / fitness step, loaded once (nothing but the audio
     // prefetch is in flight inside the loop, so its waits never drain the prefetch)
@@ -1208,10 +1229,10 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     // bins, which is what keeps N = 1024 at three wavefronts per SIMD with two rows in flight
     __shared__ float tgt_s[MODE == 1 ? M + 1 : 1];
     if constexpr (MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) tgt_s[lane + kWave * q] = target[lane + kWave * q];
-        __syncthreads();
+        for (int k = threadIdx.x; k < M; k += W * kWave) tgt_s[k] = target[k];
     }
+    if constexpr (MODE == 1 || W > 1) __syncthreads(); // (the only workgroup barrier: target and row counter are there)
+    if (ind >= p_len) return;
 
     // rows are read 16 bytes per lane: pair index lane + 64 h holds complex points 2(lane+64h), +1
     constexpr int Q = E / 2;
@@ -1225,7 +1246,7 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     // Three row buffers rotate (no copies): two rows are in flight beside the one being
     // transformed - a row's transform is shorter than the loaded memory latency, and the registers
     // are there (168 = three wavefronts per SIMD).
-    auto request = [&](float4 (&dst)[Q], uint32_t r) { // rows past the end re-read the last valid one
+    auto request = [&](float4 (&dst)[Q], uint32_t r) { // rows past the end re-read the current one
 #ifdef SOTS_ABL_FFT_CACHED_ROWS
         const float4 *__restrict__ in = reinterpret_cast<const float4 *>(audio + (size_t)((r < p_len ? r : ind) & 511u) * pitch); // timing ablation: rows from L2
 #else
@@ -1237,13 +1258,27 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
     // transforms the row in `cur` (individual `ind`) after requesting row ind + 2 grid into `fill`
 #ifdef SOTS_STAMP
     unsigned long long st_wait = 0, st_fft = 0, st_tail = 0, st_rows = 0;
+    const uint32_t st_slot = blockIdx.x * W + wave;
     const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime(); // 100 MHz, common to the whole chip
     const unsigned long long st_begin_clk = __builtin_amdgcn_s_memtime();
 #define SOTS_FFT_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define SOTS_FFT_T(var)
 #endif
-    auto process = [&](float4 (&cur)[Q], float4 (&fill)[Q]) {
+    uint32_t pend = 0, dealt = 2; // the take on its way (lane 0) / W = 1: takes so far
+    auto next_take = [&]() {
+        if constexpr (W == 1) return dealt++;
+        else {
+            const uint32_t t = __builtin_amdgcn_readfirstlane(pend);
+            if (lane == 0) pend = atomicAdd(&next_s, 1u); // answered during this row's transform
+            return t;
+        }
+    };
+    if constexpr (W > 1) {
+        if (lane == 0) pend = atomicAdd(&next_s, 1u);
+    }
+    // transforms the row in `cur` (row `ind`) after requesting this wavefront's next take into `fill`; returns that row
+    auto process = [&](float4 (&cur)[Q], float4 (&fill)[Q]) -> uint32_t {
         SOTS_FFT_T(t0);
 #ifdef SOTS_STAMP
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q) : "memory"); // the row in `cur` has landed (the newer request may still fly)
@@ -1256,9 +1291,10 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
                 cur[h] = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         }
-        request(fill, ind + 2 * gridDim.x);
+        const uint32_t filled = blockIdx.x + next_take() * grid;
+        request(fill, filled);
         float2 z[E]; // z[s] = Z[lane + 64 s]
-        fft_forward<M>(cur, lds, tw, twr, lane, z);
+        fft_forward<M, W == 1>(cur, lds, tw, twr, lane, z);
         SOTS_FFT_T(t2);
         // bin M/2 = conj Z[M/2]; Z[M/2] = Z[0 + 64 (E/2)] is lane 0's slot E/2, and only lane 0 (k = 0) uses it
         const float2 x_half = make_float2(z[E / 2].x, -z[E / 2].y);
@@ -1286,34 +1322,37 @@ __global__ __launch_bounds__(kWave) void k_fft(const float *__restrict__ audio, 
             float acc = wave_sum(acc2.x + acc2.y);
             if (lane == 0) fitness[ind] = acc;
         }
-        ind += gridDim.x;
-        __syncthreads(); // single-wavefront workgroup: orders this row's LDS reads before the next row's writes
+        wave_lds_sync<W == 1>(); // orders this row's LDS reads before the next row's writes
 #ifdef SOTS_STAMP
         {
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            if (st_rows == 0 && lane == 0 && blockIdx.x < 512) g_stamps[3 * 8192 + blockIdx.x * 16 + 7] = t0 - st_begin_clk; // prologue
+            if (st_rows == 0 && lane == 0 && st_slot < 512) g_stamps[3 * 8192 + st_slot * 16 + 7] = t0 - st_begin_clk; // prologue
             st_wait += t1 - t0, st_fft += t2 - t1, st_tail += t3 - t2, st_rows += 1;
-            if (lane == 0 && blockIdx.x < 512) {
-                g_stamps[3 * 8192 + blockIdx.x * 16 + 0] = st_wait;
-                g_stamps[3 * 8192 + blockIdx.x * 16 + 1] = st_fft;
-                g_stamps[3 * 8192 + blockIdx.x * 16 + 2] = st_tail;
-                g_stamps[3 * 8192 + blockIdx.x * 16 + 3] = st_rows;
-                g_stamps[3 * 8192 + blockIdx.x * 16 + 4] = st_begin;
-                g_stamps[3 * 8192 + blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memrealtime();
-                g_stamps[3 * 8192 + blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime() - st_begin_clk;
+            if (lane == 0 && st_slot < 512) {
+                g_stamps[3 * 8192 + st_slot * 16 + 0] = st_wait;
+                g_stamps[3 * 8192 + st_slot * 16 + 1] = st_fft;
+                g_stamps[3 * 8192 + st_slot * 16 + 2] = st_tail;
+                g_stamps[3 * 8192 + st_slot * 16 + 3] = st_rows;
+                g_stamps[3 * 8192 + st_slot * 16 + 4] = st_begin;
+                g_stamps[3 * 8192 + st_slot * 16 + 5] = __builtin_amdgcn_s_memrealtime();
+                g_stamps[3 * 8192 + st_slot * 16 + 6] = __builtin_amdgcn_s_memtime() - st_begin_clk;
             }
         }
 #endif
-        return ind < p_len;
+        return filled;
     };
     float4 b0[Q], b1[Q], b2[Q];
-    request(b0, ind);
+    uint32_t r0 = ind, r1 = blockIdx.x + (W + wave) * grid, r2; // the rows in the three buffers
+    request(b0, r0);
     asm volatile("" ::: "memory"); // keep the two requests in this order (the loop's waits count on it)
-    request(b1, ind + gridDim.x);
-    while (true) {
-        if (!process(b0, b2)) break;
-        if (!process(b1, b0)) break;
-        if (!process(b2, b1)) break;
+    request(b1, r1);
+    while (true) { // (takes only grow: a wavefront whose next row is past the end has no later one either)
+        ind = r0, r2 = process(b0, b2);
+        if (r1 >= p_len) break;
+        ind = r1, r0 = process(b1, b0);
+        if (r2 >= p_len) break;
+        ind = r2, r1 = process(b2, b1);
+        if (r0 >= p_len) break;
     }
 }
 
@@ -2724,10 +2763,26 @@ static bool x_from(uint32_t log2n) { return log2n >= SOTS_X_MIN && log2n <= 13; 
     }
 #define SOTS_X_GRID(K, L, MODE) resident_grid(K, x_waves<L, MODE>() * kWave, (p + x_waves<L, MODE>() - 1) / x_waves<L, MODE>(), num_cus, &occ_x[L])
 
+// N = 1024 from four rows per wavefront: one workgroup of twelve wavefronts per CU, rows dealt as the wavefronts ask (k_fft)
+static bool fft_wide(uint32_t p, uint32_t log2n, uint32_t num_cus)
+{
+#ifdef SOTS_FFT_NO_WIDE
+    return false; // (experiments: the one-wavefront workgroups at every size)
+#else
+    return log2n == 10 && p >= 4u * fft_wide_waves<10>() * (num_cus ? num_cus : 256u);
+#endif
+}
+#define SOTS_WIDE_GRID(K, slot) resident_grid(K, fft_wide_waves<10>() * kWave, (p + fft_wide_waves<10>() - 1) / fft_wide_waves<10>(), num_cus, &oc->wide[slot])
+
 hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const float2 *twiddle,
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus, OccCache *oc)
 {
     int *occ = oc->fft;
+    if (fft_wide(p, log2n, num_cus) && !x_from(log2n)) {
+        constexpr int W = fft_wide_waves<10>();
+        k_fft<10, 0, false, W><<<SOTS_WIDE_GRID((k_fft<10, 0, false, W>), 0), W * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch);
+        return hipGetLastError();
+    }
     if (x_from(log2n)) {
         int *occ_x = oc->x_fft;
 #define CALL(L) k_fft_x<L, 0, false><<<SOTS_X_GRID((k_fft_x<L, 0, false>), L, 0), x_waves<L, 0>() * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
@@ -2775,6 +2830,12 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
             SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         }
+        return hipGetLastError();
+    }
+    if (fft_wide(p, log2n, num_cus)) {
+        constexpr int W = fft_wide_waves<10>();
+        if (window) k_fft<10, 1, true, W><<<SOTS_WIDE_GRID((k_fft<10, 1, true, W>), 1), W * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch);
+        else k_fft<10, 1, false, W><<<SOTS_WIDE_GRID((k_fft<10, 1, false, W>), 2), W * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch);
         return hipGetLastError();
     }
     if (window) {

@@ -647,6 +647,13 @@ def test_full_size_properties_config4_shard(pkg, O):
     full_size_properties(pkg, O, 32768, 98304, 0, 10)
 
 
+def test_full_size_properties_ragged_rows_dealt_inside_the_workgroup(pkg, O):
+    """From four rows per wavefront k_fft runs as ONE workgroup of twelve wavefronts per CU whose rows are dealt out as the
+    wavefronts ask for them (an LDS counter): a population that is a multiple of the recombination block only (12320 rows: the workgroups own
+    48 or 49 rows, the last takes run past the end) - every row evaluated exactly once, 64 of them against the oracle."""
+    full_size_properties(pkg, O, 3104, 9216, 0, 10)
+
+
 def test_island_rows_roundtrip(pkg, O):
     es, ref = make_pair(pkg, O, 64, 192, 0, 10)
     rng = np.random.default_rng(9)

@@ -33,4 +33,11 @@ print(f"  workgroups 0..{len(a) - 1}: first starts at 0, last starts at {(b.max(
       f"median residence {np.median(e - b) / 100:.1f} us")
 print(f"  shader clock while resident: {np.median(a[:, 6] / (e - b)) * 100 / 1e3:.2f} GHz (cycles / 100 MHz ticks)")
 print(f"  prologue (tables, twiddles, first requests) until the first row starts: {np.median(a[:, 7]):.0f} cycles; resident {np.median(a[:, 6]):.0f} cycles")
+W = 12  # wavefronts per workgroup of the wide kernel (k_fft<10, ., ., 12>); slots are workgroup * W + wavefront
+if len(a) % W == 0 and P >= 4 * W * 256:
+    by = lambda v: np.array2string(np.median(v.reshape(-1, W), axis=0), precision=1, floatmode="fixed", max_line_width=200)
+    print("  by wavefront of the workgroup (median over workgroups):")
+    print("   rows       ", by(rows))
+    print("   end (us)   ", by((e - t0) / 100))
+    print("   cycles/row ", by(a[:, 6] / rows))
 es.close()
