@@ -2763,13 +2763,17 @@ static bool x_from(uint32_t log2n) { return log2n >= SOTS_X_MIN && log2n <= 13; 
     }
 #define SOTS_X_GRID(K, L, MODE) resident_grid(K, x_waves<L, MODE>() * kWave, (p + x_waves<L, MODE>() - 1) / x_waves<L, MODE>(), num_cus, &occ_x[L])
 
-// N = 1024 from four rows per wavefront: one workgroup of twelve wavefronts per CU, rows dealt as the wavefronts ask (k_fft)
+// N = 1024 from one row per resident wavefront (P >= 12 x CUs): one workgroup of twelve wavefronts per CU, rows dealt as
+// the wavefronts ask (k_fft); 15.7 -> 14.7 us at P = 8192 already, level at 4096
 static bool fft_wide(uint32_t p, uint32_t log2n, uint32_t num_cus)
 {
 #ifdef SOTS_FFT_NO_WIDE
     return false; // (experiments: the one-wavefront workgroups at every size)
 #else
-    return log2n == 10 && p >= 4u * fft_wide_waves<10>() * (num_cus ? num_cus : 256u);
+#ifndef SOTS_FFT_WIDE_ROWS
+#define SOTS_FFT_WIDE_ROWS 1u
+#endif
+    return log2n == 10 && p >= SOTS_FFT_WIDE_ROWS * fft_wide_waves<10>() * (num_cus ? num_cus : 256u);
 #endif
 }
 #define SOTS_WIDE_GRID(K, slot) resident_grid(K, fft_wide_waves<10>() * kWave, (p + fft_wide_waves<10>() - 1) / fft_wide_waves<10>(), num_cus, &oc->wide[slot])
