@@ -280,10 +280,12 @@ __device__ __forceinline__ void wavetable_ready()
     __syncthreads();
 }
 
-#ifdef SOTS_STAMP
-// Diagnostic build only (never the shipped library): per-wavefront shader cycles and 100 MHz
-// ticks around the synthesis loop, read back with sots_debug_stamps().
+#if defined(SOTS_STAMP) || defined(SOTS_STAMP_ENDS)
+// Diagnostic builds only (never the shipped library): per-wavefront shader cycles and 100 MHz
+// ticks, read back with sots_debug_stamps().
 __device__ unsigned long long g_stamps[2 * 16384];
+#endif
+#ifdef SOTS_STAMP
 struct StampScope {
     unsigned long long t0, r0;
     uint32_t slot;
@@ -1195,7 +1197,8 @@ __device__ __forceinline__ float wave_sum(float v)
 // Rows of N <= 1024 only (longer rows: k_fft_x).
 // W: wavefronts per workgroup, each transforming rows of its own.  W = 1: workgroup b takes rows b, b + grid, ... - small
 // populations, a wavefront wherever there is room.  W = 12 (N = 1024: what the registers let a CU hold, ONE workgroup per
-// CU): the workgroup's rows b + t grid are dealt to its wavefronts as they ask (an LDS counter).  The SIMD issues for its
+// CU): the workgroup's rows b + t grid are dealt to its wavefronts as they ask (an LDS counter; every grid-th row, so that
+// the whole GPU reads one moving window of the audio: a contiguous block of rows per workgroup is 8 % slower).  The SIMD issues for its
 // oldest wavefront first: with a fixed deal the three wavefronts of a SIMD finish their equal shares one after the
 // other and the last one runs alone, far below the issue rate (k_fft_x below has the numbers).
 template <int LOG2N> constexpr int fft_wide_waves() { return LOG2N == 10 ? 12 : 16; }
@@ -1265,6 +1268,12 @@ __global__ __launch_bounds__(W *kWave) void k_fft(const float *__restrict__ audi
 #else
 #define SOTS_FFT_T(var)
 #endif
+#ifdef SOTS_STAMP_ENDS
+    // light stamps (no per-phase timers: the register allocation stays the product's): when every wavefront starts its
+    // first row and ends, and how many rows it took (tools/fft_ends_probe.py)
+    const unsigned long long se_begin = __builtin_amdgcn_s_memrealtime();
+    uint32_t se_rows = 0;
+#endif
     uint32_t pend = 0, dealt = 2; // the take on its way (lane 0) / W = 1: takes so far
     auto next_take = [&]() {
         if constexpr (W == 1) return dealt++;
@@ -1293,6 +1302,9 @@ __global__ __launch_bounds__(W *kWave) void k_fft(const float *__restrict__ audi
         }
         const uint32_t filled = blockIdx.x + next_take() * grid;
         request(fill, filled);
+#ifdef SOTS_STAMP_ENDS
+        ++se_rows;
+#endif
         float2 z[E]; // z[s] = Z[lane + 64 s]
         fft_forward<M, W == 1>(cur, lds, tw, twr, lane, z);
         SOTS_FFT_T(t2);
@@ -1354,6 +1366,12 @@ __global__ __launch_bounds__(W *kWave) void k_fft(const float *__restrict__ audi
         ind = r2, r1 = process(b2, b1);
         if (r0 >= p_len) break;
     }
+#ifdef SOTS_STAMP_ENDS
+    if (lane == 0 && blockIdx.x * W + wave < 4096) {
+        unsigned long long *o = g_stamps + (blockIdx.x * W + wave) * 4;
+        o[0] = se_begin, o[1] = __builtin_amdgcn_s_memrealtime(), o[2] = se_rows, o[3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((16 - 1) << 11)); // HW_ID: wave, SIMD, CU, SH, SE
+    }
+#endif
 }
 
 // fitnessPopulation on materialised spectrum rows; same bin -> lane assignment and
@@ -3049,7 +3067,7 @@ hipError_t launch_unpack_rows(hipStream_t st, float *values, float *steps, float
 
 } // namespace sots
 
-#ifdef SOTS_STAMP
+#if defined(SOTS_STAMP) || defined(SOTS_STAMP_ENDS)
 extern "C" int sots_debug_stamps(unsigned long long *host, size_t n)
 {
     if (n > 2 * 16384) n = 2 * 16384;
