@@ -752,6 +752,8 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         // more genes the serial per-lane variation costs more than the launch it saves (measured).
         const bool fuse_variation = ctx->fuse_variation >= 0 ? ctx->fuse_variation == 1
                                                              : (ctx->pd.d <= 4 && ctx->P >= 192u * (ctx->num_cus ? ctx->num_cus : 256u)) ||
+                                                                   // a few individuals per CU: k_synth_tp makes them, a thread per gene
+                                                                   (ctx->allow_cut && synth_time_parallel(ctx->cfg.synth_kind, ctx->P, ctx->num_cus)) ||
                                                                    // small populations of the 2- and 3-operator voices: the cut kernel's helper wavefronts (launch_synth);
                                                                    // with 8 genes it is a draw (204 = 204 us at P = 1024, 373 against 368 at 32768)
                                                                    (ctx->pd.d <= 6 && ctx->cfg.synth_kind != SOTS_SYNTH_TRIPLE_PAR && ctx->allow_cut && ctx->P <= 128u * (ctx->num_cus ? ctx->num_cus : 256u)) ||

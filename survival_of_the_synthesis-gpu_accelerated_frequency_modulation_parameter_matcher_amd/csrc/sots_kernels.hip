@@ -807,6 +807,150 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
 }
 
 // ------------------------------------------------------------------------------------
+// Series voices of SMALL populations (a few individuals per CU): the time axis in the lanes.
+//
+// k_synth above puts an individual in a lane and pays its ten to twenty vector instructions per sample and operator whether
+// one lane is alive or sixty-four; with a few individuals per CU almost all of that is arithmetic on dead lanes.  But only the
+// PHASE of an operator is a recurrence over the samples - pos[n+1] = wrap(pos[n] + inc[n]), three dependent instructions -
+// while everything else (the table read at pos[n], t mul + off, times c, times the gain) is independent per sample.  So
+// operator s has TWO wavefronts here, and per block of 64 samples
+//   * its SCAN wavefront, lane = individual, reads the 64 increments of its individual (operator 0: a constant) and writes
+//     the 64 phases in their place - the reference's additions and wraps, in its order;
+//   * its EVALUATION wavefront, lane = SAMPLE, takes individual after individual: table value at the phase, then either the
+//     next operator's increment c (t mul + off) into that operator's buffer or gain t to the audio row (a whole 256-byte
+//     piece of a row per instruction).
+// A pipeline of 2 OPS stages, one block and one workgroup barrier per tick, three buffers per operator in rotation (the
+// evaluation of block b reads a buffer in the tick in which block b + 2's increments are written).  Every sample sees exactly the
+// reference's operations, unfused: bit-identical to k_synth and the oracle.  What is left per sample is the latency of the
+// three dependent instructions of a scan (~30 cycles; k_synth: ~90): profiles/r03_experiments.md.
+// ------------------------------------------------------------------------------------
+constexpr int kTpRow = 64 + 4; // floats per (individual, block) row: the scan's 16-byte accesses of neighbouring lanes on different banks
+// individuals per workgroup: three rows per operator each, in the 31 KiB beside the table that the genes leave (19 / 12 / 9
+// for 2, 3, 4 operators: populations up to 4864 / 3072 / 2304 on 256 CUs)
+template <int KIND> constexpr int tp_max_individuals() { return (31 * 1024) / (VoiceShape<KIND>::OPS * 3 * kTpRow * 4); }
+
+template <int KIND>
+__global__ __launch_bounds__(2 * VoiceShape<KIND>::OPS *kWave) void k_synth_tp(const float *__restrict__ values,
+                                                                                const float *__restrict__ wavetable,
+                                                                                float *__restrict__ audio, SynthParams sp,
+                                                                                uint32_t p_len, uint32_t n, uint32_t pitch,
+                                                                                uint32_t per_group, Variation var)
+{
+    constexpr int OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D, IMAX = tp_max_individuals<KIND>();
+    constexpr uint32_t THREADS = 2 * OPS * kWave;
+    static_assert(VoiceShape<KIND>::J == 1, "series voices");
+    __shared__ float tab[kWavetableSize];
+    __shared__ __attribute__((aligned(16))) float buf[OPS][3][IMAX][kTpRow]; // [operator][block mod 3][individual][sample]: increments, then phases
+    __shared__ float made[IMAX * D];
+    request_wavetable(tab, wavetable);
+    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const bool scans = wave < OPS;           // wavefronts 0 .. OPS-1 scan, OPS .. 2 OPS - 1 evaluate
+    const int s = scans ? wave : wave - OPS; // this wavefront's operator
+    const uint32_t first = blockIdx.x * per_group;
+    const uint32_t count = first >= p_len ? 0u : (p_len - first < per_group ? p_len - first : per_group); // individuals here (<= IMAX)
+
+    // the individuals: read, or made here (fused generation loop: one gene per thread)
+    if (var.vin) {
+        for (uint32_t t = threadIdx.x; t < count * D; t += THREADS) {
+            const uint32_t i1 = first + t / D, g1 = t % D;
+            const uint32_t src = recombine_source(i1, g1, var.pd);
+            float x = var.vin[src], st = var.sin[src];
+            mutate_gene(x, st, var.pd.gid_base + i1, g1, var.generation, var.pd, var.mc);
+            var.vout[(size_t)i1 * D + g1] = x;
+            var.sout[(size_t)i1 * D + g1] = st;
+            made[t] = x;
+        }
+    } else {
+        for (uint32_t t = threadIdx.x; t < count * D; t += THREADS) made[t] = values[(size_t)first * D + t];
+    }
+    __syncthreads();
+    // lane i < count: individual first + i.  scaleParams and the per-operator constants as in k_synth
+    float pr[D];
+#pragma unroll
+    for (int g = 0; g < D; ++g) {
+        pr[g] = lane < count ? made[lane * D + g] : 0.0f;
+        pr[g] = sp.pmin[g] + pr[g] * (sp.pmax[g] - sp.pmin[g]); // min + v*(max-min), ocl_program.cl:297
+    }
+    float inc0, mul_next = 0.0f, off_next = 0.0f, gain; // mul / off: what the evaluation of operator s applies for operator s + 1
+    if constexpr (KIND == SOTS_SYNTH_2OP) { // Evolutionary_Strategy.hpp:372-401
+        inc0 = c * pr[0];
+        if (s == 0) mul_next = pr[0] * pr[1], off_next = pr[2];
+        gain = pr[3];
+    } else { // series, :407-445 (the 4-operator voice adds one more modulator stage)
+        inc0 = c * pr[1];
+#pragma unroll
+        for (int o = 1; o < OPS; ++o)
+            if (s == o - 1) mul_next = pr[2 * (o - 1)] * pr[2 * (o - 1) + 1], off_next = pr[2 * (o - 1) + 3];
+        gain = pr[2 * (OPS - 1)] * pr[2 * (OPS - 1) + 1];
+    }
+    wavetable_ready();
+
+    const uint32_t blocks = n / kWave;
+    float pos = 0.0f; // (scan wavefronts) this operator's phase of individual `lane`
+    for (uint32_t tick = 0; tick < blocks + 2 * OPS - 1; ++tick) {
+        // scan of operator s: block tick - 2 s; its evaluation: one tick later
+        const uint32_t k = tick - 2u * (uint32_t)s - (scans ? 0u : 1u);
+        if (k < blocks) {
+            float(*rows)[kTpRow] = buf[s][k % 3u];
+            if (scans) {
+                if (lane < count) { // lane = individual: phases in place of increments, four samples per access
+                    float4 *row = reinterpret_cast<float4 *>(rows[lane]);
+                    if (s == 0) {
+#pragma unroll
+                        for (int q = 0; q < kWave / 4; ++q) {
+                            float4 o;
+                            o.x = pos, pos += inc0, wrap_hi(pos);
+                            o.y = pos, pos += inc0, wrap_hi(pos);
+                            o.z = pos, pos += inc0, wrap_hi(pos);
+                            o.w = pos, pos += inc0, wrap_hi(pos);
+                            row[q] = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < kWave / 4; ++q) {
+                            const float4 v = row[q];
+                            float4 o;
+                            o.x = pos, pos += v.x, wrap_both(pos);
+                            o.y = pos, pos += v.y, wrap_both(pos);
+                            o.z = pos, pos += v.z, wrap_both(pos);
+                            o.w = pos, pos += v.w, wrap_both(pos);
+                            row[q] = o;
+                        }
+                    }
+                }
+            } else { // lane = sample
+                const uint32_t sample = k * kWave + lane;
+                // four individuals at a time: their phases, then their table values, are asked for together
+                float(*next)[kTpRow] = buf[s + 1 < OPS ? s + 1 : 0][k % 3u];
+                for (uint32_t i0 = 0; i0 < count; i0 += 4) {
+                    float ph[4], t[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) ph[j] = rows[i0 + j < count ? i0 + j : i0][lane];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) t[j] = tab_at<true>(tab, ph[j]);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t i = i0 + j;
+                        if (i >= count) break;
+                        if (s < OPS - 1) {
+                            const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mul_next), (int)i));
+                            const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(off_next), (int)i));
+                            next[i][lane] = c * (t[j] * m + o); // the next operator's increment, unfused
+                        } else {
+                            const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gain), (int)i));
+                            audio[(size_t)(first + i) * pitch + sample] = g * t[j];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // applyWindowPopulation, ocl_program.cl:566-586.  The table is the reference's double
 // window (Evolutionary_Strategy.hpp:308-317) rounded once to fp32.
 // ------------------------------------------------------------------------------------
@@ -2656,6 +2800,23 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
     return hipGetLastError();
 }
 
+// Where k_synth_tp runs: series voices with at most 8 (2 operators: 22-27 us of synthesis against 32-35 at N = 1024; from 16
+// individuals per CU k_synth's cut kernels win), 12 or 9 (3, 4 operators: what fits beside the table) individuals per CU
+bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
+{
+#ifdef SOTS_SYNTH_NO_TP
+    return false;
+#else
+    const uint32_t share = (p + (num_cus ? num_cus : 256u) - 1) / (num_cus ? num_cus : 256u);
+    switch (kind) {
+    case SOTS_SYNTH_2OP: return share <= 8u;
+    case SOTS_SYNTH_3OP_SERIES: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_3OP_SERIES>();
+    case SOTS_SYNTH_4OP_SERIES: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_4OP_SERIES>();
+    default: return false;
+    }
+#endif
+}
+
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
                         uint32_t num_cus, const Variation *variation, bool allow_cut)
@@ -2668,6 +2829,15 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     // of the population, up to one wavefront per SIMD; larger populations loop.  Up to two
     // wavefronts' worth per CU, a series voice is cut into two wavefronts per 64 individuals.
     const uint32_t share = (p + cus - 1) / cus;
+    // a few individuals per CU: the time axis in the lanes (k_synth_tp), two wavefronts per operator
+    if (allow_cut && synth_time_parallel(kind, p, num_cus)) {
+        switch (kind) {
+        case SOTS_SYNTH_2OP: k_synth_tp<SOTS_SYNTH_2OP><<<(p + share - 1) / share, 4 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        case SOTS_SYNTH_3OP_SERIES: k_synth_tp<SOTS_SYNTH_3OP_SERIES><<<(p + share - 1) / share, 6 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        default: k_synth_tp<SOTS_SYNTH_4OP_SERIES><<<(p + share - 1) / share, 8 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        }
+        return hipGetLastError();
+    }
     uint32_t waves = (share + kWave - 1) / kWave;
     waves = waves < 1 ? 1 : waves > (uint32_t)kSynthWaves ? (uint32_t)kSynthWaves : waves;
     const bool cut = allow_cut && waves <= 2 && kind != SOTS_SYNTH_TRIPLE_PAR;
