@@ -807,7 +807,7 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
 }
 
 // ------------------------------------------------------------------------------------
-// Series voices of SMALL populations (a few individuals per CU): the time axis in the lanes.
+// SMALL populations (a few individuals per CU), every voice: the time axis in the lanes.
 //
 // k_synth above puts an individual in a lane and pays its ten to twenty vector instructions per sample and operator whether
 // one lane is alive or sixty-four; with a few individuals per CU almost all of that is arithmetic on dead lanes.  But only the
@@ -825,29 +825,35 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
 // three dependent instructions of a scan (~30 cycles; k_synth: ~90): profiles/r03_experiments.md.
 // ------------------------------------------------------------------------------------
 constexpr int kTpRow = 64 + 4; // floats per (individual, block) row: the scan's 16-byte accesses of neighbouring lanes on different banks
-// individuals per workgroup: three rows per operator each, in the 31 KiB beside the table that the genes leave (19 / 12 / 9
-// for 2, 3, 4 operators: populations up to 4864 / 3072 / 2304 on 256 CUs)
-template <int KIND> constexpr int tp_max_individuals() { return (31 * 1024) / (VoiceShape<KIND>::OPS * 3 * kTpRow * 4); }
+// individuals per workgroup: three rows per operator each (and, for the voice of three parallel chains, two rows for each of
+// the two products that wait for the third), in the 31 KiB beside the table that the genes leave: 19 / 12 / 9 for 2, 3, 4
+// operators in series (populations up to 4864 / 3072 / 2304 on 256 CUs), 5 for the triple voice (1280)
+template <int KIND> constexpr int tp_max_individuals()
+{
+    return (31 * 1024) / ((VoiceShape<KIND>::J * VoiceShape<KIND>::OPS * 3 + (VoiceShape<KIND>::J > 1 ? 2 * (VoiceShape<KIND>::J - 1) : 0)) * kTpRow * 4);
+}
 
 template <int KIND>
-__global__ __launch_bounds__(2 * VoiceShape<KIND>::OPS *kWave) void k_synth_tp(const float *__restrict__ values,
+__global__ __launch_bounds__(2 * VoiceShape<KIND>::J *VoiceShape<KIND>::OPS *kWave) void k_synth_tp(const float *__restrict__ values,
                                                                                 const float *__restrict__ wavetable,
                                                                                 float *__restrict__ audio, SynthParams sp,
                                                                                 uint32_t p_len, uint32_t n, uint32_t pitch,
                                                                                 uint32_t per_group, Variation var)
 {
-    constexpr int OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D, IMAX = tp_max_individuals<KIND>();
-    constexpr uint32_t THREADS = 2 * OPS * kWave;
-    static_assert(VoiceShape<KIND>::J == 1, "series voices");
+    // J > 1 (the voice of three 2-operator chains, averaged): every chain has its own pipeline; chains 1 ... J-1 leave gain t
+    // in LDS and chain 0, which runs one tick behind them, adds the products in the reference's order and divides
+    constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D, IMAX = tp_max_individuals<KIND>();
+    constexpr uint32_t THREADS = 2 * J * OPS * kWave;
     __shared__ float tab[kWavetableSize];
-    __shared__ __attribute__((aligned(16))) float buf[OPS][3][IMAX][kTpRow]; // [operator][block mod 3][individual][sample]: increments, then phases
+    __shared__ __attribute__((aligned(16))) float buf[J * OPS][3][IMAX][kTpRow]; // [chain, operator][block mod 3][individual][sample]: increments, then phases
+    __shared__ float prod[J > 1 ? J - 1 : 1][2][J > 1 ? IMAX : 1][J > 1 ? kTpRow : 1]; // [chain - 1][block parity]: gain t of chains 1 ... J-1
     __shared__ float made[IMAX * D];
     request_wavetable(tab, wavetable);
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const bool scans = wave < OPS;           // wavefronts 0 .. OPS-1 scan, OPS .. 2 OPS - 1 evaluate
-    const int s = scans ? wave : wave - OPS; // this wavefront's operator
+    const bool scans = wave < J * OPS; // the first J OPS wavefronts scan, the others evaluate
+    const int jo = scans ? wave : wave - J * OPS, jc = jo / OPS, s = jo % OPS; // this wavefront's chain and operator
     const uint32_t first = blockIdx.x * per_group;
     const uint32_t count = first >= p_len ? 0u : (p_len - first < per_group ? p_len - first : per_group); // individuals here (<= IMAX)
 
@@ -871,13 +877,22 @@ __global__ __launch_bounds__(2 * VoiceShape<KIND>::OPS *kWave) void k_synth_tp(c
 #pragma unroll
     for (int g = 0; g < D; ++g) {
         pr[g] = lane < count ? made[lane * D + g] : 0.0f;
-        pr[g] = sp.pmin[g] + pr[g] * (sp.pmax[g] - sp.pmin[g]); // min + v*(max-min), ocl_program.cl:297
+        const int sc = KIND == SOTS_SYNTH_TRIPLE_PAR ? (g & 3) : g; // the triple voice scales all three chains by entries 0..3, Evolutionary_Strategy.hpp:453-455
+        pr[g] = sp.pmin[sc] + pr[g] * (sp.pmax[sc] - sp.pmin[sc]); // min + v*(max-min), ocl_program.cl:297
     }
     float inc0, mul_next = 0.0f, off_next = 0.0f, gain; // mul / off: what the evaluation of operator s applies for operator s + 1
     if constexpr (KIND == SOTS_SYNTH_2OP) { // Evolutionary_Strategy.hpp:372-401
         inc0 = c * pr[0];
         if (s == 0) mul_next = pr[0] * pr[1], off_next = pr[2];
         gain = pr[3];
+    } else if constexpr (KIND == SOTS_SYNTH_TRIPLE_PAR) { // :457-494
+        inc0 = 0.0f, gain = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj)
+            if (jc == jj) {
+                inc0 = c * pr[4 * jj], gain = pr[4 * jj + 3];
+                if (s == 0) mul_next = pr[4 * jj] * pr[4 * jj + 1], off_next = pr[4 * jj + 2];
+            }
     } else { // series, :407-445 (the 4-operator voice adds one more modulator stage)
         inc0 = c * pr[1];
 #pragma unroll
@@ -889,11 +904,12 @@ __global__ __launch_bounds__(2 * VoiceShape<KIND>::OPS *kWave) void k_synth_tp(c
 
     const uint32_t blocks = n / kWave;
     float pos = 0.0f; // (scan wavefronts) this operator's phase of individual `lane`
-    for (uint32_t tick = 0; tick < blocks + 2 * OPS - 1; ++tick) {
+    constexpr uint32_t LAG0 = J > 1 ? 1u : 0u; // chain 0 of a parallel voice: one tick behind the others
+    for (uint32_t tick = 0; tick < blocks + 2 * OPS - 1 + LAG0; ++tick) {
         // scan of operator s: block tick - 2 s; its evaluation: one tick later
-        const uint32_t k = tick - 2u * (uint32_t)s - (scans ? 0u : 1u);
+        const uint32_t k = tick - 2u * (uint32_t)s - (scans ? 0u : 1u) - (jc == 0 ? LAG0 : 0u);
         if (k < blocks) {
-            float(*rows)[kTpRow] = buf[s][k % 3u];
+            float(*rows)[kTpRow] = buf[jo][k % 3u];
             if (scans) {
                 if (lane < count) { // lane = individual: phases in place of increments, four samples per access
                     float4 *row = reinterpret_cast<float4 *>(rows[lane]);
@@ -923,7 +939,7 @@ __global__ __launch_bounds__(2 * VoiceShape<KIND>::OPS *kWave) void k_synth_tp(c
             } else { // lane = sample
                 const uint32_t sample = k * kWave + lane;
                 // four individuals at a time: their phases, then their table values, are asked for together
-                float(*next)[kTpRow] = buf[s + 1 < OPS ? s + 1 : 0][k % 3u];
+                float(*next)[kTpRow] = buf[s + 1 < OPS ? jo + 1 : 0][k % 3u];
                 for (uint32_t i0 = 0; i0 < count; i0 += 4) {
                     float ph[4], t[4];
 #pragma unroll
@@ -940,7 +956,10 @@ __global__ __launch_bounds__(2 * VoiceShape<KIND>::OPS *kWave) void k_synth_tp(c
                             next[i][lane] = c * (t[j] * m + o); // the next operator's increment, unfused
                         } else {
                             const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gain), (int)i));
-                            audio[(size_t)(first + i) * pitch + sample] = g * t[j];
+                            if constexpr (J == 1) audio[(size_t)(first + i) * pitch + sample] = g * t[j];
+                            else if (jc != 0) prod[jc - 1][k & 1u][i][lane] = g * t[j];
+                            else // the reference's sum, in its order, and its division (== (float)(double(sum) / 3.0), :493)
+                                audio[(size_t)(first + i) * pitch + sample] = (g * t[j] + prod[0][k & 1u][i][lane] + prod[J > 2 ? 1 : 0][k & 1u][i][lane]) / 3.0f;
                         }
                     }
                 }
@@ -2800,8 +2819,9 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
     return hipGetLastError();
 }
 
-// Where k_synth_tp runs: series voices with at most 8 (2 operators: 22-27 us of synthesis against 32-35 at N = 1024; from 16
-// individuals per CU k_synth's cut kernels win), 12 or 9 (3, 4 operators: what fits beside the table) individuals per CU
+// Where k_synth_tp runs: at most 8 individuals per CU for the 2-operator voice (22-27 us of synthesis against 32-35 at
+// N = 1024; from 16 per CU k_synth's cut kernels win), 12 / 9 / 5 for 3 / 4 operators in series / three parallel chains (what
+// fits beside the table)
 bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
 {
 #ifdef SOTS_SYNTH_NO_TP
@@ -2812,6 +2832,7 @@ bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
     case SOTS_SYNTH_2OP: return share <= 8u;
     case SOTS_SYNTH_3OP_SERIES: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_3OP_SERIES>();
     case SOTS_SYNTH_4OP_SERIES: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_4OP_SERIES>();
+    case SOTS_SYNTH_TRIPLE_PAR: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_TRIPLE_PAR>();
     default: return false;
     }
 #endif
@@ -2834,6 +2855,7 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         switch (kind) {
         case SOTS_SYNTH_2OP: k_synth_tp<SOTS_SYNTH_2OP><<<(p + share - 1) / share, 4 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
         case SOTS_SYNTH_3OP_SERIES: k_synth_tp<SOTS_SYNTH_3OP_SERIES><<<(p + share - 1) / share, 6 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        case SOTS_SYNTH_TRIPLE_PAR: k_synth_tp<SOTS_SYNTH_TRIPLE_PAR><<<(p + share - 1) / share, 12 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
         default: k_synth_tp<SOTS_SYNTH_4OP_SERIES><<<(p + share - 1) / share, 8 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
         }
         return hipGetLastError();

@@ -119,6 +119,43 @@ def test_synthesise_bitexact(pkg, O, kind, log2n):
     es.close()
 
 
+@pytest.mark.parametrize("kind,log2n", [(0, 10), (1, 11), (2, 10), (3, 11)])
+@pytest.mark.parametrize("parents,offspring", [(288, 896), (32, 64), (512, 1536)])
+def test_synthesise_time_in_the_lanes_ragged_workgroups_bitexact(pkg, O, kind, log2n, parents, offspring):
+    """A few individuals per CU: k_synth_tp (a scanning and an evaluating wavefront per operator, lane = sample in the
+    evaluation).  1184 individuals are five per workgroup with four in the last (one batch of four plus one, and a partly
+    filled batch), 96 one per workgroup, 2048 eight (two full batches; the triple voice, at most five per CU, runs
+    k_synth there): every row bit for bit against the oracle, both from stored genes and - fused loop - from genes made
+    inside the kernel (one thread per gene)."""
+    es, ref = make_pair(pkg, O, parents, offspring, kind, log2n)
+    es.init_population(0)
+    ref.init_population(0)
+    v, s, _ = es.read_population()
+    _, tv = target_audio(O, kind, es.N)
+    v[0], v[1], v[2] = tv, 0.0, 1.0
+    v[es.P - 1] = tv
+    es.write_population(v, s, None)
+    ref.write_population(v, s, None)
+    es.synthesise()
+    ref.evaluate()
+    assert np.array_equal(es.read_audio(), ref.audio())
+    es.close()
+    # the fused loop makes the individuals inside the kernel: same audio and same population as the separate stages
+    a, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    b, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
+    tgt, _ = target_audio(O, kind, a.N)
+    for e in (a, b):
+        e.set_target_audio(tgt)
+        e.init_population(0)
+    a.execute_generations(1)
+    b.recombine(); b.mutate(); b.synthesise()
+    assert np.array_equal(a.read_audio(), b.read_audio())
+    b.window(); b.fft(); b.fitness(); b.sort(); b.rotate()
+    for x, y in zip(a.read_population(), b.read_population()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_synthesise_two_op_large_population_uses_lane_per_individual_kernel(pkg, O):
     """Above 128 individuals per CU the 2-op voice runs k_synth (one lane per individual, four
     wavefronts per workgroup, looping over tiles) instead of the chain cut into two wavefronts; rows are

@@ -3,3 +3,4 @@ run() { echo "== $*"; timeout -k 10 300 python3 bench.py "$@" --steps 400 --warm
 for p in "16 48" "256 768" "512 1536" "1024 3072"; do set -- $p; run --parents $1 --offspring $2; done
 for p in "16 16" "256 768" "512 1536"; do set -- $p; run --parents $1 --offspring $2 --synth 3op_series --log2n 11; done
 for p in "16 48" "256 768" "512 1536"; do set -- $p; run --parents $1 --offspring $2 --synth 4op_series --log2n 12; done
+for p in "16 48" "256 768"; do set -- $p; run --parents $1 --offspring $2 --synth triple_parallel --log2n 10; done
