@@ -68,7 +68,7 @@ struct Variation {
 // needs no synchronisation (a process-wide cache would be shared by every device and thread).
 struct OccCache {
     int fft[16], fitness[16], fused_win[16], fused_raw[16];
-    int x_fft[16], x_fitness[16], x_fused_win[16], x_fused_raw[16];
+    int x_fft[16], x_fitness[16], x_fused_win[16], x_fused_raw[16], x_small[16];
     int wide[4]; // k_fft with twelve wavefronts per workgroup: spectrum writer, fused with / without window
 };
 

@@ -2528,13 +2528,16 @@ __device__ __forceinline__ void x_lane_stage_pairs(v2f_t (&x)[E], v2f_t w)
     }
 }
 
-template <int LOG2N, int MODE, bool WIN>
-__global__ __launch_bounds__((x_waves<LOG2N, MODE>() * kWave)) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
+// WG: wavefronts per workgroup.  The default fills a CU with one workgroup (the tables are made once per workgroup); a SMALL
+// population - fewer such workgroups than CUs - runs workgroups of four instead, a wavefront per SIMD on four times as many
+// CUs: a row is then transformed at a lone wavefront's pace, not at a quarter of it (1024 rows of N = 4096: 24.6 -> ... us).
+template <int LOG2N, int MODE, bool WIN, int WG = x_waves<LOG2N, MODE>()>
+__global__ __launch_bounds__((WG * kWave)) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                                    const float *__restrict__ target, float *__restrict__ fitness,
                                                                    const float2 *__restrict__ tw, const float *__restrict__ window,
                                                                    uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N, MODE>();
+    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = WG;
     constexpr int S2 = E + 2, S1 = E + 4; // lane strides of the float2 / float tables (16-byte reads, spread over the banks)
     __shared__ __attribute__((aligned(16))) float2 tw2_s[kWave * S2], tws_s[kWave * S2], win_s[WIN ? kWave * S2 : 1];
     __shared__ __attribute__((aligned(16))) float tgt_s[MODE == 1 ? kWave * S1 : 4];
@@ -3035,6 +3038,13 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
     if (x_from(log2n)) {
         if (window) {
             int *occ_x = oc->x_fused_win;
+            if ((p + x_waves<12>() - 1) / x_waves<12>() < (num_cus ? num_cus : 256u)) { // a small population: a wavefront per SIMD
+                int *occ_s = oc->x_small;
+#define CALL(L) k_fft_x<L, 1, true, 4><<<resident_grid((k_fft_x<L, 1, true, 4>), 4 * kWave, (p + 3) / 4, num_cus, &occ_s[L]), 4 * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+                SOTS_DISPATCH_X(log2n, CALL)
+#undef CALL
+                return hipGetLastError();
+            }
 #define CALL(L) k_fft_x<L, 1, true><<<SOTS_X_GRID((k_fft_x<L, 1, true>), L, 1), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
             SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
