@@ -833,8 +833,13 @@ template <int KIND> constexpr int tp_max_individuals()
     return (31 * 1024) / ((VoiceShape<KIND>::J * VoiceShape<KIND>::OPS * 3 + (VoiceShape<KIND>::J > 1 ? 2 * (VoiceShape<KIND>::J - 1) : 0)) * kTpRow * 4);
 }
 
+// evaluating wavefronts per operator: two for the series voices (from about eight individuals per CU the evaluation of a
+// block takes longer than its scan: the two take every other batch of four), one for the triple voice (six operators)
+template <int KIND> constexpr int tp_eval_waves() { return VoiceShape<KIND>::J == 1 ? 2 : 1; }
+template <int KIND> constexpr int tp_waves() { return VoiceShape<KIND>::J * VoiceShape<KIND>::OPS * (1 + tp_eval_waves<KIND>()); }
+
 template <int KIND>
-__global__ __launch_bounds__(2 * VoiceShape<KIND>::J *VoiceShape<KIND>::OPS *kWave) void k_synth_tp(const float *__restrict__ values,
+__global__ __launch_bounds__(tp_waves<KIND>() * kWave) void k_synth_tp(const float *__restrict__ values,
                                                                                 const float *__restrict__ wavetable,
                                                                                 float *__restrict__ audio, SynthParams sp,
                                                                                 uint32_t p_len, uint32_t n, uint32_t pitch,
@@ -843,7 +848,8 @@ __global__ __launch_bounds__(2 * VoiceShape<KIND>::J *VoiceShape<KIND>::OPS *kWa
     // J > 1 (the voice of three 2-operator chains, averaged): every chain has its own pipeline; chains 1 ... J-1 leave gain t
     // in LDS and chain 0, which runs one tick behind them, adds the products in the reference's order and divides
     constexpr int J = VoiceShape<KIND>::J, OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D, IMAX = tp_max_individuals<KIND>();
-    constexpr uint32_t THREADS = 2 * J * OPS * kWave;
+    constexpr int NE = tp_eval_waves<KIND>();
+    constexpr uint32_t THREADS = tp_waves<KIND>() * kWave;
     __shared__ float tab[kWavetableSize];
     __shared__ __attribute__((aligned(16))) float buf[J * OPS][3][IMAX][kTpRow]; // [chain, operator][block mod 3][individual][sample]: increments, then phases
     __shared__ float prod[J > 1 ? J - 1 : 1][2][J > 1 ? IMAX : 1][J > 1 ? kTpRow : 1]; // [chain - 1][block parity]: gain t of chains 1 ... J-1
@@ -852,8 +858,9 @@ __global__ __launch_bounds__(2 * VoiceShape<KIND>::J *VoiceShape<KIND>::OPS *kWa
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const bool scans = wave < J * OPS; // the first J OPS wavefronts scan, the others evaluate
-    const int jo = scans ? wave : wave - J * OPS, jc = jo / OPS, s = jo % OPS; // this wavefront's chain and operator
+    const bool scans = wave < J * OPS; // the first J OPS wavefronts scan, the others evaluate (NE per operator)
+    const int jo = scans ? wave : (wave - J * OPS) / NE, jc = jo / OPS, s = jo % OPS; // this wavefront's chain and operator
+    const uint32_t ev = scans ? 0u : (uint32_t)((wave - J * OPS) % NE);                // ... and which of its evaluators
     const uint32_t first = blockIdx.x * per_group;
     const uint32_t count = first >= p_len ? 0u : (p_len - first < per_group ? p_len - first : per_group); // individuals here (<= IMAX)
 
@@ -940,7 +947,7 @@ __global__ __launch_bounds__(2 * VoiceShape<KIND>::J *VoiceShape<KIND>::OPS *kWa
                 const uint32_t sample = k * kWave + lane;
                 // four individuals at a time: their phases, then their table values, are asked for together
                 float(*next)[kTpRow] = buf[s + 1 < OPS ? jo + 1 : 0][k % 3u];
-                for (uint32_t i0 = 0; i0 < count; i0 += 4) {
+                for (uint32_t i0 = 4u * ev; i0 < count; i0 += 4u * NE) {
                     float ph[4], t[4];
 #pragma unroll
                     for (uint32_t j = 0; j < 4; ++j) ph[j] = rows[i0 + j < count ? i0 + j : i0][lane];
@@ -2825,6 +2832,9 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 // Where k_synth_tp runs: at most 8 individuals per CU for the 2-operator voice (22-27 us of synthesis against 32-35 at
 // N = 1024; from 16 per CU k_synth's cut kernels win), 12 / 9 / 5 for 3 / 4 operators in series / three parallel chains (what
 // fits beside the table)
+#ifndef SOTS_TP_2OP_MAX
+#define SOTS_TP_2OP_MAX 16
+#endif
 bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
 {
 #ifdef SOTS_SYNTH_NO_TP
@@ -2832,7 +2842,7 @@ bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
 #else
     const uint32_t share = (p + (num_cus ? num_cus : 256u) - 1) / (num_cus ? num_cus : 256u);
     switch (kind) {
-    case SOTS_SYNTH_2OP: return share <= 8u;
+    case SOTS_SYNTH_2OP: return share <= (uint32_t)SOTS_TP_2OP_MAX;
     case SOTS_SYNTH_3OP_SERIES: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_3OP_SERIES>();
     case SOTS_SYNTH_4OP_SERIES: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_4OP_SERIES>();
     case SOTS_SYNTH_TRIPLE_PAR: return share <= (uint32_t)tp_max_individuals<SOTS_SYNTH_TRIPLE_PAR>();
@@ -2856,10 +2866,10 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
     // a few individuals per CU: the time axis in the lanes (k_synth_tp), two wavefronts per operator
     if (allow_cut && synth_time_parallel(kind, p, num_cus)) {
         switch (kind) {
-        case SOTS_SYNTH_2OP: k_synth_tp<SOTS_SYNTH_2OP><<<(p + share - 1) / share, 4 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
-        case SOTS_SYNTH_3OP_SERIES: k_synth_tp<SOTS_SYNTH_3OP_SERIES><<<(p + share - 1) / share, 6 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
-        case SOTS_SYNTH_TRIPLE_PAR: k_synth_tp<SOTS_SYNTH_TRIPLE_PAR><<<(p + share - 1) / share, 12 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
-        default: k_synth_tp<SOTS_SYNTH_4OP_SERIES><<<(p + share - 1) / share, 8 * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        case SOTS_SYNTH_2OP: k_synth_tp<SOTS_SYNTH_2OP><<<(p + share - 1) / share, tp_waves<SOTS_SYNTH_2OP>() * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        case SOTS_SYNTH_3OP_SERIES: k_synth_tp<SOTS_SYNTH_3OP_SERIES><<<(p + share - 1) / share, tp_waves<SOTS_SYNTH_3OP_SERIES>() * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        case SOTS_SYNTH_TRIPLE_PAR: k_synth_tp<SOTS_SYNTH_TRIPLE_PAR><<<(p + share - 1) / share, tp_waves<SOTS_SYNTH_TRIPLE_PAR>() * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
+        default: k_synth_tp<SOTS_SYNTH_4OP_SERIES><<<(p + share - 1) / share, tp_waves<SOTS_SYNTH_4OP_SERIES>() * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, share, var); break;
         }
         return hipGetLastError();
     }
@@ -3184,28 +3194,37 @@ hipError_t launch_sort(hipStream_t st, const float *vin, const float *sin, const
 
 // keys buffer: n_pad 64-bit keys (full sort) or n_pad fitness-bit words + n_pad indices (selection),
 // followed by the selection's per-tile samples
-size_t sort_keys_bytes(uint32_t p)
+// The selection's key arrays: the population padded to a power of two and to at least kSelMinTiles tiles (the rank kernel
+// holds one sample per lane and more: 16 tiles x 4 samples); a population of 2048 ... 8192 simply has tiles of nothing but
+// padding keys behind its own (they sort last, stage one quantum each and move nothing)
+static uint32_t sel_pad(uint32_t p)
 {
     const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    return n_pad < kSelMinTiles * kSelTile ? kSelMinTiles * kSelTile : n_pad;
+}
+
+size_t sort_keys_bytes(uint32_t p)
+{
+    const uint32_t n_pad = p > kSortSmall ? sel_pad(p) : next_pow2(p < 2 ? 2 : p);
     return (size_t)n_pad * sizeof(uint64_t) + (size_t)2 * kSelMaxTiles * kSelSamples * sizeof(uint32_t);
 }
 
-// The selection applies from kSelMinTiles tiles of 1024 keys (P > 8192) while at most half of the rows are wanted
-// (beyond that nearly everything would be staged and the full sort is the better plan).  Up to 64 tiles (P <= 65536)
-// the rank kernel works on the 1024-key tiles; from 128 to 256 tiles (P <= 262144) they are first merged four by four
+// The selection applies to every population that does not fit k_sort_small's one launch (P > 1024; round 3: it used to start at
+// 8192, the three launches of the tile sort below that took 20-23 us where the selection's two take 15) while at most half of
+// the rows are wanted (beyond that nearly everything would be staged and the full sort is the better plan).  Up to 64 tiles
+// (P <= 65536) the rank kernel works on the 1024-key tiles; at 128 tiles (P <= 131072) they are first merged four by four
 // (k_sel_merge4), which quarters its work; larger populations take the two-level full sort.
 constexpr uint32_t kSelDirectTiles = 64, kSelMergedTiles = 128;
 bool select_applies(uint32_t p, uint32_t need)
 {
-    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
-    const uint32_t tiles = n_pad / kSelTile;
-    return tiles >= kSelMinTiles && tiles <= kSelMergedTiles && need >= 1 && (uint64_t)need * 2 <= p;
+    const uint32_t tiles = sel_pad(p) / kSelTile;
+    return p > kSortSmall && tiles <= kSelMergedTiles && need >= 1 && (uint64_t)need * 2 <= p;
 }
 
 // scratch of the merged plan: the 4096-key tiles (bits, indices) and their samples
 size_t select_scratch_bytes(uint32_t p)
 {
-    const uint32_t n_pad = next_pow2(p < 2 ? 2 : p);
+    const uint32_t n_pad = sel_pad(p);
     return (size_t)n_pad * 2 * sizeof(uint32_t) + (size_t)2 * kSelMaxTiles * kSelSamples * sizeof(uint32_t);
 }
 
@@ -3215,7 +3234,7 @@ hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, con
 {
     if (!select_applies(p, need)) return hipErrorInvalidValue;
     const SortExchange ex = exchange ? *exchange : SortExchange{};
-    const uint32_t n_pad = next_pow2(p);
+    const uint32_t n_pad = sel_pad(p);
     const uint32_t tiles = n_pad / kSelTile;
     uint32_t *kbits = reinterpret_cast<uint32_t *>(keys), *kidx = kbits + n_pad, *samples = kidx + n_pad;
     k_sel_tiles<<<tiles, kSelTile, 0, st>>>(fin, kbits, kidx, samples, p);

@@ -397,7 +397,8 @@ def fitness_pattern(name, P, rng):
 
 SELECT_CASES = [
     # parents, offspring, kind, pattern
-    (1024, 3072, 0, "random"), (2048, 6144, 1, "tile_skew"), (6000 - 6000 % 32, 18000 - 18000 % 32, 0, "random"),
+    (1024, 3072, 0, "random"), (2048, 6144, 1, "tile_skew"), (512, 1536, 0, "random"), (512, 1536, 2, "specials"), (288, 896, 0, "few_values"),
+    (768, 2304, 3, "clones"), (1024, 1024, 0, "random"), (1056, 1024, 0, "random"), (6000 - 6000 % 32, 18000 - 18000 % 32, 0, "random"),
     (16384, 49152, 0, "random"), (16384, 49152, 0, "ascending"), (16384, 49152, 0, "descending"),
     (16384, 49152, 0, "constant"), (16384, 49152, 0, "few_values"), (16384, 49152, 0, "tile_skew"),
     (16384, 49152, 0, "converged"), (16384, 49152, 2, "specials"), (64, 65472, 0, "random"), (32768, 32768, 0, "tile_skew"),
@@ -427,7 +428,7 @@ def test_select_places_exactly_the_rows_recombination_reads(pkg, O, parents, off
     perm = O.sort_perm(f)
     assert np.array_equal(gf[:S], f[perm][:S], equal_nan=True)
     assert np.array_equal(gv[:S], v[perm][:S]) and np.array_equal(gs[:S], s[perm][:S])
-    if 8192 < P <= 131072:    # 16 to 128 tiles of 1024 keys; outside that the population is sorted in full
+    if 1024 < P <= 131072 and 2 * S <= P:    # up to 128 tiles of 1024 keys; outside that the population is sorted in full
         assert np.all(gf[S:] == -7.0) and np.all(gv[S:] == -7.0) and np.all(gs[S:] == -7.0), "rows beyond S were written"
     # the rest of the order on demand, from the untouched unsorted half
     es.set_sort_mode(pkg.capi.SORT_LAZY_TAIL)
