@@ -78,7 +78,7 @@ enum sots_sort_mode {
     SOTS_SORT_LAZY_TAIL = 0, /* default: each generation places rows 0..S-1, in order and bit-identical to the full
                               * sort; rows S..P-1 are produced, from the still intact unsorted half, by the first
                               * call that looks at them (read/write population, any sots_stage_*, packing more
-                              * than S elites).  A population outside 8192 < P <= 131072 or with S > P/2 is sorted in full.
+                              * than S elites).  A population outside 1024 < P <= 131072 or with S > P/2 is sorted in full.
                               * Calls that WRITE rows (stages, write_population, init) end the pending state. */
     SOTS_SORT_FULL = 1,      /* the reference's behaviour: every generation sorts all P rows
                               * (ocl_program.cl:664-711, Evolutionary_Strategy.hpp:108-124) */

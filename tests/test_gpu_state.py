@@ -20,7 +20,7 @@ def make(pkg, O, parents, offspring, log2n=10, **kw):
     return es
 
 
-# 4096 + 12288: the selection applies (P > 8192, S <= P/2), so the fused loop leaves a pending tail behind
+# 4096 + 12288: the selection applies (P > 1024, S <= P/2), so the fused loop leaves a pending tail behind
 @pytest.mark.parametrize("parents,offspring", [(4096, 12288), (64, 192)])
 def test_init_population_after_a_run_is_a_fresh_population(pkg, O, parents, offspring):
     """the lazy-sort state of the LAST run must not be completed into the rows of a freshly
