@@ -56,6 +56,7 @@ struct sots_ctx {
     void *sort_scratch = nullptr;
     uint32_t rows_capacity = 0;
     OccCache occ{};
+    float *x_image = nullptr; // k_fft_x's tables (N >= 2048), rebuilt with every target
     // selection state: after the fused loop's partial sort only rows [0, tail_first) of the current half
     // are in place; the unsorted half it came from is intact until the next generation starts
     uint32_t sort_mode = SOTS_SORT_LAZY_TAIL;
@@ -230,7 +231,7 @@ void free_ctx(sots_ctx *ctx)
         for (hipEvent_t e : all) (void)hipEventDestroy(e);
     }
     void *bufs[] = {ctx->values, ctx->steps, ctx->fitness, ctx->audio, ctx->spectrum, ctx->target,
-                    ctx->wavetable, ctx->window, ctx->rows, ctx->twiddle, ctx->keys, ctx->sort_scratch};
+                    ctx->wavetable, ctx->window, ctx->rows, ctx->twiddle, ctx->keys, ctx->sort_scratch, ctx->x_image};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -415,6 +416,7 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     CREATE_HIP(hipMalloc((void **)&ctx->window, (size_t)ctx->N * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&ctx->twiddle, (size_t)ctx->N * sizeof(float2)));
     CREATE_HIP(hipMalloc((void **)&ctx->keys, sort_keys_bytes(ctx->P)));
+    if (ctx->log2n >= 11 && x_table_bytes(ctx->log2n)) CREATE_HIP(hipMalloc((void **)&ctx->x_image, x_table_bytes(ctx->log2n)));
     {
         const size_t a = sort_scratch_bytes(ctx->P), b = select_scratch_bytes(ctx->P);
         CREATE_HIP(hipMalloc(&ctx->sort_scratch, a > b ? a : b));
@@ -472,6 +474,10 @@ int sots_set_target_spectrum(sots_ctx *ctx, const float *magnitudes, uint32_t nu
         return fail(ctx, SOTS_ERR_SIZE, "target spectrum needs %u bins, got %u", ctx->N / 2, num_bins);
     if (int rc = bind_device(ctx)) return rc;
     SOTS_HIP(ctx, hipMemcpyAsync(ctx->target, magnitudes, (size_t)num_bins * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->x_image) { // long rows: the fused spectral kernel's tables, in the layout it reads them in
+        SOTS_HIP(ctx, launch_x_tables(ctx->stream, ctx->x_image, ctx->twiddle, ctx->window, ctx->target, ctx->log2n));
+        ctx->occ.x_image = ctx->x_image;
+    }
     SOTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->target_set = true;
     return SOTS_OK;

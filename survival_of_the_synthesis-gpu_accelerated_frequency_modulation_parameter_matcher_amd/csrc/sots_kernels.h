@@ -70,6 +70,8 @@ struct OccCache {
     int fft[16], fitness[16], fused_win[16], fused_raw[16];
     int x_fft[16], x_fitness[16], x_fused_win[16], x_fused_raw[16], x_small[16];
     int wide[4]; // k_fft with twelve wavefronts per workgroup: spectrum writer, fused with / without window
+    // device memory of the context: the fused long-row kernel's tables as they lie in LDS (launch_x_tables; null = the workgroups make them)
+    const float *x_image;
 };
 
 // ---- variation ----
@@ -102,6 +104,8 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
 hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *target, float *fitness,
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus, OccCache *occ);
 // audio[P][pitch] (x window when window != nullptr) x target -> fitness[P]; no spectrum in memory
+size_t x_table_bytes(uint32_t log2n);
+hipError_t launch_x_tables(hipStream_t st, float *image, const float2 *twiddle, const float *window, const float *target, uint32_t log2n);
 hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *window, const float *target,
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
                               float inv_n, float inv_wf, uint32_t num_cus, OccCache *occ);

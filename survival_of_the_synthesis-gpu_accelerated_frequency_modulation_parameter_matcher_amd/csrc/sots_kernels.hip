@@ -2538,16 +2538,23 @@ __device__ __forceinline__ void x_lane_stage_pairs(v2f_t (&x)[E], v2f_t w)
 // WG: wavefronts per workgroup.  The default fills a CU with one workgroup (the tables are made once per workgroup); a SMALL
 // population - fewer such workgroups than CUs - runs workgroups of four instead, a wavefront per SIMD on four times as many
 // CUs: a row is then transformed at a lone wavefront's pace, not at a quarter of it (1024 rows of N = 4096: 24.6 -> ... us).
+// floats of the per-(lane, register) tables as they lie in LDS: step-2 twiddles, split twiddles, window (float2 each), target
+template <int LOG2N> constexpr int x_table_floats() { return 3 * 2 * kWave * (x_points<LOG2N>() + 2) + kWave * (x_points<LOG2N>() + 4); }
+
+// `image` (fused kernel with window only; may be null): the four tables as they lie in LDS, made once per target by
+// k_x_tables - the workgroups then copy them in by LDS-DMA, one round trip, instead of four dependent-index loads per entry
 template <int LOG2N, int MODE, bool WIN, int WG = x_waves<LOG2N, MODE>()>
 __global__ __launch_bounds__((WG * kWave)) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                                    const float *__restrict__ target, float *__restrict__ fitness,
                                                                    const float2 *__restrict__ tw, const float *__restrict__ window,
-                                                                   uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
+                                                                   uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch,
+                                                                   const float *__restrict__ image)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = WG;
     constexpr int S2 = E + 2, S1 = E + 4; // lane strides of the float2 / float tables (16-byte reads, spread over the banks)
-    __shared__ __attribute__((aligned(16))) float2 tw2_s[kWave * S2], tws_s[kWave * S2], win_s[WIN ? kWave * S2 : 1];
-    __shared__ __attribute__((aligned(16))) float tgt_s[MODE == 1 ? kWave * S1 : 4];
+    __shared__ __attribute__((aligned(16))) float xt_s[x_table_floats<LOG2N>()]; // (the variants without window or target leave theirs unused)
+    float2 *const tw2_s = reinterpret_cast<float2 *>(xt_s), *const tws_s = tw2_s + kWave * S2, *const win_s = tws_s + kWave * S2;
+    float *const tgt_s = reinterpret_cast<float *>(win_s + kWave * S2);
     __shared__ uint32_t next_s; // the workgroup's rows are dealt out as its wavefronts ask for them (below)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -2556,6 +2563,13 @@ __global__ __launch_bounds__((WG * kWave)) void k_fft_x(const float *__restrict_
     const unsigned long long xs_begin = __builtin_amdgcn_s_memrealtime(), xs_begin_clk = __builtin_amdgcn_s_memtime();
     unsigned long long xs_wait = 0, xs_rows = 0, xs_split = 0;
 #endif
+    if (MODE == 1 && WIN && image != nullptr) {
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        static_assert(x_table_floats<LOG2N>() % 256 == 0, "whole 1 KiB pieces");
+        for (uint32_t ch = wave; ch < (uint32_t)x_table_floats<LOG2N>() / 256u; ch += W)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(image) + ch * 256u + lane * 4u, (lds_ptr_t)(xt_s + ch * 256u), 16, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): this wavefront's pieces have landed (the barrier below covers the others')
+    } else
     for (uint32_t e = tid; e < kWave * E; e += W * kWave) {
         const uint32_t l = e / E, r = e % E;
         const uint32_t q = __brev(r) >> (32 - EB), pp = __brev(l) >> 26, k = q + E * pp;
@@ -2750,6 +2764,23 @@ __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fitness_x(const fl
         });
         acc = wave_sum(acc);
         if (lane == 0) fitness[row] = acc;
+    }
+}
+// the table image of the fused kernel (k_fft_x<LOG2N, 1, true>), entry by entry what its workgroups would make themselves
+template <int LOG2N>
+__global__ __launch_bounds__(256) void k_x_tables(float *__restrict__ image, const float2 *__restrict__ tw,
+                                                  const float *__restrict__ window, const float *__restrict__ target)
+{
+    constexpr int E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), S2 = E + 2, S1 = E + 4;
+    float2 *const tw2_s = reinterpret_cast<float2 *>(image), *const tws_s = tw2_s + kWave * S2, *const win_s = tws_s + kWave * S2;
+    float *const tgt_s = reinterpret_cast<float *>(win_s + kWave * S2);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < (uint32_t)(kWave * E); e += gridDim.x * blockDim.x) {
+        const uint32_t l = e / E, r = e % E;
+        const uint32_t q = __brev(r) >> (32 - EB), pp = __brev(l) >> 26, k = q + E * pp;
+        tw2_s[l * S2 + r] = tw[2u * l * q];
+        tws_s[l * S2 + r] = tw[k];
+        win_s[l * S2 + r] = reinterpret_cast<const float2 *>(window)[l + kWave * r];
+        tgt_s[l * S1 + r] = target[k];
     }
 }
 #pragma clang fp contract(off)
@@ -3012,7 +3043,7 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
     }
     if (x_from(log2n)) {
         int *occ_x = oc->x_fft;
-#define CALL(L) k_fft_x<L, 0, false><<<SOTS_X_GRID((k_fft_x<L, 0, false>), L, 0), x_waves<L, 0>() * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch)
+#define CALL(L) k_fft_x<L, 0, false><<<SOTS_X_GRID((k_fft_x<L, 0, false>), L, 0), x_waves<L, 0>() * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch, nullptr)
         SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         return hipGetLastError();
@@ -3040,6 +3071,28 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
     return hipGetLastError();
 }
 
+// the table image the fused long-row kernel copies in (bytes: x_table_bytes; rebuilt whenever the target changes)
+size_t x_table_bytes(uint32_t log2n)
+{
+    switch (log2n) {
+    case 10: return x_table_floats<10>() * sizeof(float);
+    case 11: return x_table_floats<11>() * sizeof(float);
+    case 12: return x_table_floats<12>() * sizeof(float);
+    case 13: return x_table_floats<13>() * sizeof(float);
+    default: return 0;
+    }
+}
+hipError_t launch_x_tables(hipStream_t st, float *image, const float2 *twiddle, const float *window, const float *target, uint32_t log2n)
+{
+    if (!x_from(log2n)) return hipSuccess;
+    hipError_t e = hipMemsetAsync(image, 0, x_table_bytes(log2n), st); // (the padding between the lanes' rows)
+    if (e != hipSuccess) return e;
+#define CALL(L) k_x_tables<L><<<8, 256, 0, st>>>(image, twiddle, window, target)
+    SOTS_DISPATCH_X(log2n, CALL)
+#undef CALL
+    return hipGetLastError();
+}
+
 hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *window, const float *target,
                               float *fitness, const float2 *twiddle, uint32_t p, uint32_t log2n, uint32_t pitch,
                               float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
@@ -3050,17 +3103,17 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
             int *occ_x = oc->x_fused_win;
             if ((p + x_waves<12>() - 1) / x_waves<12>() < (num_cus ? num_cus : 256u)) { // a small population: a wavefront per SIMD
                 int *occ_s = oc->x_small;
-#define CALL(L) k_fft_x<L, 1, true, 4><<<resident_grid((k_fft_x<L, 1, true, 4>), 4 * kWave, (p + 3) / 4, num_cus, &occ_s[L]), 4 * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+#define CALL(L) k_fft_x<L, 1, true, 4><<<resident_grid((k_fft_x<L, 1, true, 4>), 4 * kWave, (p + 3) / 4, num_cus, &occ_s[L]), 4 * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch, oc->x_image)
                 SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
                 return hipGetLastError();
             }
-#define CALL(L) k_fft_x<L, 1, true><<<SOTS_X_GRID((k_fft_x<L, 1, true>), L, 1), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch)
+#define CALL(L) k_fft_x<L, 1, true><<<SOTS_X_GRID((k_fft_x<L, 1, true>), L, 1), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch, oc->x_image)
             SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         } else {
             int *occ_x = oc->x_fused_raw;
-#define CALL(L) k_fft_x<L, 1, false><<<SOTS_X_GRID((k_fft_x<L, 1, false>), L, 1), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch)
+#define CALL(L) k_fft_x<L, 1, false><<<SOTS_X_GRID((k_fft_x<L, 1, false>), L, 1), x_waves<L>() * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, nullptr, p, inv_n, inv_wf, pitch, nullptr)
             SOTS_DISPATCH_X(log2n, CALL)
 #undef CALL
         }
