@@ -8,14 +8,21 @@ from test_gpu_parity import FIT_RTOL, PMAX, WILD, fit_atol, make_pair, target_au
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+# SOTS_FUZZ_SEED / SOTS_FUZZ_CASES: another draw, or a longer one (the sizes sit on both sides of the points where kernels
+# hand over: one-launch sort / selection at 1024, k_synth_tp / k_synth at 5 ... 16 individuals per CU, the wide k_fft at 3072)
 CASES = []
-_rng = np.random.default_rng(20261004)
-for _ in range(18):
+_rng = np.random.default_rng(int(os.environ.get("SOTS_FUZZ_SEED", "20261004")))
+_sizes = [33, 65, 130, 257, 515, 1000, 1031, 4099, 16390, 33000]
+if "SOTS_FUZZ_SEED" in os.environ or "SOTS_FUZZ_CASES" in os.environ:
+    _sizes += [1290, 2050, 2310, 3080, 4870, 8200]
+for _ in range(int(os.environ.get("SOTS_FUZZ_CASES", "18"))):
     kind = int(_rng.integers(0, 4))
     log2n = int(_rng.choice([9, 10, 10, 11, 12]))
-    p = int(_rng.choice([33, 65, 130, 257, 515, 1000, 1031, 4099, 16390, 33000]))
+    p = int(_rng.choice(_sizes))
     if log2n >= 11:
-        p = min(p, 1031)       # keep the oracle to seconds
+        p = min(p, 1031 if "SOTS_FUZZ_CASES" not in os.environ else 2310)       # keep the oracle to seconds
     parents = max(1, p // 4)
     CASES.append((kind, log2n, parents, p - parents, bool(_rng.integers(0, 2))))
 
