@@ -9,6 +9,20 @@
 // One deliberate difference: the reference builds a 6-field record when a timer fired at
 // most once and CSV_Logger then drops it (Benchmarker.hpp:145-157, CSV_Logger.hpp:30-31);
 // here every timer produces a full 7-field row.
+//
+// Pinned against the reference's own class: tests/golden/benchmarker_rows_v1*.csv are the rows
+// /root/reference/Benchmarker.hpp + CSV_Logger.hpp write, compiled as they stand, for the call
+// sequence of tests/golden/benchmarker_sequence.inc (tests/golden/make_benchmarker_golden.sh);
+// tests/test_host_cpu.py feeds this class the same sequence and compares field for field.
+// What that pin fixed here: elapsedTimer resets ONLY the count and the total, as the reference
+// does (Benchmarker.hpp:164-166) - the last duration carries over, so the first difference of
+// the next cycle is taken against the last sample of the previous one, and the difference sum
+// restarts from the previous cycle's AVERAGE (Benchmarker.hpp:151).  The reference's
+// `abs(elapsed - last)` (Benchmarker.hpp:66,104,127) names no header: under g++/libstdc++ it
+// resolves to `int abs(int)` and truncates every difference to whole milliseconds, with
+// <math.h>/<stdlib.h> in scope (MSVC, or g++ -include math.h) to the double overload.  This
+// class takes the double reading (std::fabs); both goldens are committed and the test says
+// which columns each one pins.
 #ifndef SOTS_BENCHMARKER_HPP
 #define SOTS_BENCHMARKER_HPP
 
@@ -27,7 +41,7 @@ class Benchmarker
     struct Timer {
         double start = 0.0, total = 0.0, last = 0.0;
         double maxDuration = 0.0, minDuration = 9999999.0;
-        double maxDifference = 0.0, sumDifference = 0.0;
+        double maxDifference = 0.0, sumDifference = 0.0; // sumDifference: the reference's averageDifference[]
         uint32_t count = 0;
     };
     std::map<std::string, Timer> timers_;
@@ -108,6 +122,7 @@ public:
         Timer &t = timers_[aTimer];
         const double n = t.count > 0 ? (double)t.count : 1.0;
         const double average = t.total / n;
+        if (t.count > 1) t.sumDifference /= n; // stays in the timer: the next cycle's sum starts from it (Benchmarker.hpp:151)
         if (verbose_) {
             std::cout << "Benchmarker: " << aTimer << std::endl;
             std::cout << "Total time to complete: " << t.total / 1e3 << "s" << std::endl;
@@ -117,8 +132,11 @@ public:
         }
         logger_.addRecord({aTimer, std::to_string(t.total), std::to_string(average), std::to_string(t.maxDuration),
                            std::to_string(t.minDuration), std::to_string(t.maxDifference),
-                           std::to_string(t.sumDifference / n)});
-        t = Timer();
+                           std::to_string(t.sumDifference)});
+        // reset as the reference does (Benchmarker.hpp:164-166): count and total only; maxima and minimum are
+        // re-armed by the next start/addTimer, the last duration and the difference average carry over
+        t.count = 0;
+        t.total = 0.0;
     }
     bool close()
     {

@@ -124,8 +124,10 @@ def test_one_device_group_is_the_plain_context(pkg, O):
         g.close()
 
 
-# unfused: 0 = pack and inject inside the sort kernel, overlapped schedule with ready counters polled by that kernel (default);
-# 1 = launches of their own; 2 = fused, but ordered by HIP events instead of the counters
+# unfused: 0 = pack and inject inside the sort kernel; in the overlapped schedule the HOST waits for the previous exchange's
+# `arrived` event before it enqueues the sort that takes its rows (host-gated, the default);
+# 1 = pack and inject as launches of their own; 2 = fused, but the compute stream waits for the side stream's event
+# (hipStreamWaitEvent) instead of the host
 @pytest.mark.parametrize("parents,offspring,unfused", [(2048, 6144, 0), (2048, 6144, 1), (4096, 12288, 0), (96, 160, 0), (4096, 12288, 2)])
 @pytest.mark.parametrize("world,overlap,interval", [(2, False, 1), (2, True, 1), (3, False, 2), (3, True, 1), (3, True, 2)])
 def test_group_of_islands_sharing_the_gpu_equals_host_exchange(pkg, O, world, overlap, interval, parents, offspring, unfused):
@@ -175,6 +177,93 @@ def test_group_of_islands_sharing_the_gpu_equals_host_exchange(pkg, O, world, ov
     for es in isl:
         es.close()
     g.close()
+
+
+def host_exchange_reference(pkg, target, world, gens, elites, overlap, interval, parents, offspring, kind, log2n, pmax):
+    """The same islands as plain contexts driven from ONE thread, exchanging through the blocking host calls
+    (sots_pack_elites_host / sots_inject_immigrants_host) every `interval` generations."""
+    P = parents + offspring
+    isl = []
+    for r in range(world):
+        es = pkg.HipES(parents, offspring, kind, log2n, None, pmax, seed=0x5EED0001, workgroup_size=32, gid_base=r * P)
+        es.set_target_audio(target)
+        es.init_population(0)
+        isl.append(es)
+    in_flight = None
+    for gen in range(1, gens + 1):
+        for es in isl:
+            es.execute_generations(1)
+        if gen % interval:
+            continue
+        if overlap and in_flight is not None:
+            for r, es in enumerate(isl):
+                es.inject_immigrants(np.concatenate([in_flight[q] for q in range(world) if q != r]))
+        packs = [es.pack_elites(elites) for es in isl]
+        if overlap:
+            in_flight = packs
+        else:
+            for r, es in enumerate(isl):
+                es.inject_immigrants(np.concatenate([packs[q] for q in range(world) if q != r]))
+    out = [es.read_population() for es in isl]
+    for es in isl:
+        es.close()
+    return out
+
+
+# BASELINE configs[3] and configs[4] AT THEIR STATED SIZE: eight islands (the 8-GPU run's shards) inside one group, all on
+# device 0 - the reference is single-device (Evolutionary_Strategy_OpenCL.hpp:194-226), so the host-exchange simulation is
+# the only other witness of this path.  8 x 0.55 GB of audio per side.
+FULL_SIZE = {3: (8192, 24576, 3, 12, [3520.0, 8.0] * 4, [0.3, 0.25, 0.85, 0.19, 0.89, 0.125, 0.5, 0.1]),
+             4: (32768, 98304, 0, 10, PMAX, [1450 / 3520, 3 / 8, 200 / 3520, 1.0])}
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("config", [3, 4])
+def test_world8_group_at_full_baseline_size_equals_host_exchange(pkg, O, config, overlap):
+    """configs[3]: 8 x 32768 = 262144 candidates, 4-op, N = 4096; configs[4]: 8 x 131072 = 1048576 candidates, 2-op,
+    N = 1024.  Three generations with an exchange of 16 elites per island after each: every island bit-identical to the
+    single-thread simulation, the immigrants sit where recombination reads them, every island ends sorted."""
+    parents, offspring, kind, log2n, pmax, tvals = FULL_SIZE[config]
+    world, gens, elites = 8, 3, 16
+    P = parents + offspring
+    target = O.synth(kind, tvals, [0.0] * len(tvals), pmax, 1 << log2n)
+    g = pkg.HipGroup([0] * world, elites, parents, offspring, kind, log2n, None, pmax, seed=0x5EED0001,
+                     migration_interval=1, overlap=overlap)
+    assert g.size == world and not g.uses_rccl
+    g.set_target_audio(target)
+    g.init_population(0)
+    g.execute_generations(2)
+    g.execute_generations(gens - 2)
+    g.synchronize()
+    got = [g.island(r).read_population() for r in range(world)]
+    island, fit = g.best()
+    assert fit == min(float(np.nanmin(p[2])) for p in got)
+    g.close()
+    want = host_exchange_reference(pkg, target, world, gens, elites, overlap, 1, parents, offspring, kind, log2n, pmax)
+    for r in range(world):
+        for name, x, y in zip("vsf", got[r], want[r]):
+            assert np.array_equal(x, y, equal_nan=True), f"config {config} island {r} {name}"
+    assert sum(p[2].size for p in got) == world * P == (262144 if config == 3 else 1048576)
+    n = (world - 1) * elites
+    chunks = {}  # source island -> its elite rows as each other island received them
+    for r in range(world):
+        v, s, f = got[r]
+        assert not np.array_equal(v, got[(r + 1) % world][0]), "islands are distinct streams"
+        # the last (world-1)*16 of the rows recombination reads hold the other islands' elites in rank order (of the
+        # generation just finished in the same-generation schedule, of the one before in the overlapped one: they were
+        # taken by generation 3's sort); every other row is in order
+        assert np.all(np.diff(f[:parents - n]) >= 0) and np.all(np.diff(f[parents:]) >= 0), f"island {r} not sorted"
+        sources = [q for q in range(world) if q != r]
+        for i, q in enumerate(sources):
+            lo = parents - n + i * elites
+            chunks.setdefault(q, []).append((f[lo:lo + elites], v[lo:lo + elites], s[lo:lo + elites]))
+    for q, seen in chunks.items():
+        assert len(seen) == world - 1
+        for c in seen[1:]:
+            assert all(np.array_equal(x, y) for x, y in zip(c, seen[0])), f"island {q}'s elites arrived differently"
+        assert np.all(np.diff(seen[0][0]) >= 0)
+        if not overlap:
+            assert np.array_equal(seen[0][0], got[q][2][:elites]) and np.array_equal(seen[0][1], got[q][0][:elites])
 
 
 def test_group_rejects_bad_arguments(pkg, O):

@@ -73,3 +73,35 @@ def test_benchmarker_and_csv(run):
     assert once[0] == "once" and len(once) == 7 and float(once[2]) == 7.5
     assert rows[3].startswith("wall,")
     assert (d / "raw.csv").read_text() == "a,b,\n1,2,\n"
+
+
+def test_benchmarker_rows_equal_the_reference_class(tmp_path):
+    """The one piece of the boundary the reference itself can pin: the golden CSVs are what
+    /root/reference/Benchmarker.hpp + CSV_Logger.hpp - compiled as they stand by tests/golden/make_benchmarker_golden.sh -
+    write for tests/golden/benchmarker_sequence.inc; host/Benchmarker.hpp is fed the same sequence here.
+      * benchmarker_rows_v1_absdouble.csv (the reference with the double overload of abs in scope): every row, all seven
+        fields, byte for byte - including what carries over an elapsedTimer reset (Benchmarker.hpp:151,164-166);
+      * benchmarker_rows_v1.csv (plain g++: `abs` resolves to int abs(int), Benchmarker.hpp:66,104,127): the five fields in
+        front byte for byte; its two difference columns are the truncated-to-whole-ms version of the other file's and are
+        not reproduced;
+      * the one deliberate difference: the timer that fired once is a 6-field record the reference's CSV_Logger drops
+        (Benchmarker.hpp:145-157, CSV_Logger.hpp:30-31); here it is a full row."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    exe = tmp_path / "benchmarker_driver"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", HOST, "-I", gold, "-o", str(exe),
+                           os.path.join(gold, "benchmarker_driver.cpp")])
+    out = tmp_path / "rows.csv"
+    subprocess.run([str(exe), str(out)], check=True, capture_output=True, timeout=60)
+    mine = out.read_text().splitlines()
+    once = [r for r in mine if r.startswith("once,")]
+    assert len(once) == 1 and once[0] == "once,7.500000,7.500000,7.500000,7.500000,7.500000,7.500000,"
+    mine = [r for r in mine if not r.startswith("once,")]
+    absdouble = open(os.path.join(gold, "benchmarker_rows_v1_absdouble.csv")).read().splitlines()
+    plain = open(os.path.join(gold, "benchmarker_rows_v1.csv")).read().splitlines()
+    assert len(absdouble) == len(plain) == 7 and not any(r.startswith("once,") for r in absdouble + plain)
+    assert mine == absdouble
+    for a, b in zip(mine, plain):
+        assert a.split(",")[:5] == b.split(",")[:5]
+    # the plain build's difference columns never exceed the double build's (every difference was truncated towards zero)
+    for a, b in zip(absdouble[1:], plain[1:]):
+        assert float(b.split(",")[5]) <= float(a.split(",")[5])
