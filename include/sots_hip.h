@@ -165,6 +165,9 @@ int sots_execute_generation(sots_ctx *ctx);
  * the first reader, enum sots_sort_mode).
  * The window is applied as the FFT kernel loads a row, so afterwards the audio buffer holds
  * the UN-windowed synthesis and the spectrum buffer is untouched.
+ * Only enqueues - with ONE exception: after sots_fuse_exchange_next_sort with a host_gate_event the call blocks the
+ * calling thread on that event (hipEventSynchronize) before it enqueues the last generation's sort, so the host never
+ * runs more than the kernels of one generation ahead of a gathered exchange.
  * (executeAllGenerations, ...OpenCL.hpp:542-547) */
 int sots_execute_generations(sots_ctx *ctx, uint32_t n);
 
@@ -249,7 +252,14 @@ sots_ctx *sots_group_island(sots_group *group, uint32_t i);
 int sots_group_set_target_audio(sots_group *group, const float *audio, uint32_t num_samples);
 int sots_group_set_target_spectrum(sots_group *group, const float *magnitudes, uint32_t num_bins);
 int sots_group_init_population(sots_group *group, uint32_t chunk_index);
-/* n generations on every island with the elite exchange; returns once everything is ENQUEUED */
+/* n generations on every island with the elite exchange; returns once everything is ENQUEUED.  In the overlapped
+ * schedule (SOTS_GROUP_OVERLAP without SOTS_GROUP_EVENT_WAITS, "host-gated") every island's thread waits, before it
+ * enqueues the sort of a generation in which an exchange falls due, for the PREVIOUS exchange's all-gather to have
+ * completed on the device: the call can block for up to that long, and the host runs at most one exchange interval
+ * ahead of the devices.  This schedule over RCCL has run on a one-rank communicator only (no machine with two GPUs has
+ * been available to the tests); SOTS_GROUP_EVENT_WAITS is the stream-ordered fallback.
+ * After an error the islands' populations are unspecified (a failed island stops running generations, the others go on
+ * and may receive its last good - or +inf-fitness - rows). */
 int sots_group_execute_generations(sots_group *group, uint32_t n);
 int sots_group_synchronize(sots_group *group);
 /* the island holding the lowest fitness and that fitness (blocking) */

@@ -789,15 +789,16 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         }
         src = ctx->rot;
         dst = ctx->rot ^ 1u;
+        const SortExchange *ex = with_exchange && g + 1 == n ? &exchange : nullptr;
+        // The rows this sort takes were gathered on ANOTHER stream.  The host waits for that collective here, with this
+        // generation's variation, synthesis and spectral kernels already on the stream (the GPU stays busy, and the
+        // collective - started a generation ago - is normally long done), instead of making the stream wait: on this
+        // runtime a cross-stream event wait costs the waiting stream ~18 us even when the event is complete
+        // (tools/ubench/cross_stream.hip).  A kernel launched after the host has seen the event sees the rows.
+        // In front of the sort's StageScope: a host wait is not sort-kernel time.
+        if (ex && gate) SOTS_HIP(ctx, hipEventSynchronize(gate));
         {
             StageScope t(ctx, SOTS_STAGE_SORT, true);
-            const SortExchange *ex = with_exchange && g + 1 == n ? &exchange : nullptr;
-            // The rows this sort takes were gathered on ANOTHER stream.  The host waits for that collective here, with this
-            // generation's variation, synthesis and spectral kernels already on the stream (the GPU stays busy, and the
-            // collective - started a generation ago - is normally long done), instead of making the stream wait: on this
-            // runtime a cross-stream event wait costs the waiting stream ~18 us even when the event is complete
-            // (tools/ubench/cross_stream.hip).  A kernel launched after the host has seen the event sees the rows.
-            if (ex && gate) SOTS_HIP(ctx, hipEventSynchronize(gate));
             if (select) {
                 // the rows recombination reads, in order; the rest of the order is produced on demand
                 SOTS_HIP(ctx, launch_select(ctx->stream, ctx->val(src), ctx->stp(src), ctx->fit(src), ctx->val(dst),

@@ -276,7 +276,12 @@ int exchange_inject(sots_group *g, uint32_t i, int b, bool wait_event)
 
 // n generations of island i with the exchanges that fall due.  Every island's thread runs this with the same
 // arguments and therefore takes the same branches; between two exchanges a thread only talks to its own device.
-// Nothing here waits for the GPU.  A failed island keeps taking part in barriers and collectives (the others must not hang).
+// The only wait for the GPU is the host gate of the overlapped schedule: before the sort that takes the rows of the
+// previous exchange is enqueued, the thread waits for that exchange's `arrived` event (inside sots_execute_generations,
+// with the generation's other kernels already on the stream).  A failed island keeps taking part in barriers and
+// collectives (the others must not hang): it stops running generations, its context is disarmed, and what it sends are
+// the rows of its last good exchange or - before any - rows of +inf fitness (mine[] is created that way), which no
+// recombination prefers.  After an error the group's populations are unspecified; the call returns the error.
 int run_island(sots_group *g, uint32_t i, uint32_t n, int pending, int *pending_out)
 {
     const uint32_t islands = (uint32_t)g->islands.size();
@@ -299,11 +304,13 @@ int run_island(sots_group *g, uint32_t i, uint32_t n, int pending, int *pending_
         if (run > n - k) run = n - k;
         const bool due = (g->generation + k + run) % g->interval == 0;
         const int b = (int)(x & 1u);
-        if (due && g->fused) keep(exchange_prepare_fused(g, i, b, overlap ? pending : -1));
+        if (due && g->fused && !rc) keep(exchange_prepare_fused(g, i, b, overlap ? pending : -1));
         if (!rc) {
             const int r = sots_execute_generations(g->islands[i].ctx, run);
             if (r) keep(gfail(g, r, "island %u: %s", i, sots_last_error(g->islands[i].ctx)));
         }
+        // a failed island's context must not keep an armed exchange for some later, unrelated call
+        if (rc) (void)sots_fuse_exchange_next_sort(g->islands[i].ctx, nullptr, 0, nullptr, 0, 0, 0, nullptr);
         k += run;
         if (!due) break; // (the job ended before the next exchange)
         ++x;
@@ -404,9 +411,14 @@ int sots_group_create(const sots_config *island_cfg, const int32_t *devices, uin
             CREATE_FAIL(SOTS_ERR_INVALID, "%u elites from each of %u other islands do not fit the %u parent rows recombination reads",
                         g->elites, num_devices - 1, npb * block);
         const size_t mine_bytes = (size_t)(g->elites ? g->elites : 1) * g->width * sizeof(float);
+        // rows nobody has written yet read as [+inf fitness, +inf ...]: an island that fails before its first exchange
+        // still joins the gather, and such rows sort behind everything (0x7F800000 in every float)
+        std::vector<uint32_t> inf_rows(mine_bytes / sizeof(uint32_t) * num_devices, 0x7F800000u);
         for (int b = 0; b < 2; ++b) {
             CREATE_HIP(hipMalloc((void **)&is.mine[b], mine_bytes));
             CREATE_HIP(hipMalloc((void **)&is.gathered[b], mine_bytes * num_devices));
+            CREATE_HIP(hipMemcpy(is.mine[b], inf_rows.data(), mine_bytes, hipMemcpyHostToDevice));
+            CREATE_HIP(hipMemcpy(is.gathered[b], inf_rows.data(), mine_bytes * num_devices, hipMemcpyHostToDevice));
             CREATE_HIP(hipEventCreateWithFlags(&is.packed[b], ev_flags));
             CREATE_HIP(hipEventCreateWithFlags(&is.arrived[b], ev_flags));
         }

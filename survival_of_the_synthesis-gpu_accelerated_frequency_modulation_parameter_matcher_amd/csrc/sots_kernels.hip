@@ -2867,9 +2867,9 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
     return hipGetLastError();
 }
 
-// Where k_synth_tp runs: at most 8 individuals per CU for the 2-operator voice (22-27 us of synthesis against 32-35 at
-// N = 1024; from 16 per CU k_synth's cut kernels win), 12 / 9 / 5 for 3 / 4 operators in series / three parallel chains (what
-// fits beside the table)
+// Where k_synth_tp runs: at most 16 individuals per CU for the 2-operator voice (populations up to 4096; 22-27 us of
+// synthesis against 32-35 at N = 1024; beyond that k_synth's cut kernels win), 12 / 9 / 5 for 3 / 4 operators in series /
+// three parallel chains (what fits beside the table)
 #ifndef SOTS_TP_2OP_MAX
 #define SOTS_TP_2OP_MAX 16
 #endif
@@ -3108,7 +3108,9 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
     if (x_from(log2n)) {
         if (window) {
             int *occ_x = oc->x_fused_win;
-            if ((p + x_waves<12>() - 1) / x_waves<12>() < (num_cus ? num_cus : 256u)) { // a small population: a wavefront per SIMD
+            // a small population: a wavefront per SIMD.  The threshold (fewer 16-row workgroups than CUs) was measured at
+            // N = 4096 and 2048, where x_waves is 16; N = 8192 (x_waves 8) follows it unmeasured
+            if ((p + x_waves<12>() - 1) / x_waves<12>() < (num_cus ? num_cus : 256u)) {
                 int *occ_s = oc->x_small;
 #define CALL(L) k_fft_x<L, 1, true, 4><<<resident_grid((k_fft_x<L, 1, true, 4>), 4 * kWave, (p + 3) / 4, num_cus, &occ_s[L]), 4 * kWave, 0, st>>>(audio, nullptr, target, fitness, twiddle, window, p, inv_n, inv_wf, pitch, oc->x_image)
                 SOTS_DISPATCH_X(log2n, CALL)

@@ -20,6 +20,10 @@ import torch.distributed as dist
 
 
 class IslandExchange:
+    """Elite exchange of one island (rank) over torch.distributed.  The object carries the exchange in flight (overlapped
+    schedule) and an exchange count; `restart()` drops both and belongs wherever the population is re-initialised.
+    `generation()` and `migrate_device()` also restart by themselves when they see a context whose generation count has
+    gone back to zero (es.init_population) while rows of the old population are still in flight."""
     def __init__(self, rank: int, world: int, num_elites: int, num_dims: int, device, overlap: bool = False):
         self.rank, self.world, self.E = rank, world, num_elites
         self.width = 2 * num_dims + 1
@@ -96,6 +100,11 @@ class IslandExchange:
         if self.world == 1:
             es.execute_generations(1)
             return
+        if es.generation == 0 and (self.exchanges > 0 or self.pending is not None):
+            # the population was re-initialised under us (init_population resets the generation count): rows gathered
+            # from the OLD population must not reach the new one.  Every rank initialises at the same point of the
+            # program, so every rank restarts here together.
+            self.restart()
         if not es.sort_places(self.E):  # elites beyond the rows the sort places: the separate launches
             es.execute_generations(1)
             self.migrate_device(es)
@@ -126,6 +135,8 @@ class IslandExchange:
 
     def migrate_device(self, es) -> None:
         """es: HipES whose stream is the current torch stream."""
+        if es.generation <= 1 and self.pending is not None:
+            self.restart()  # called after the first generation of a re-initialised population: drop the old one's rows
         self._exchange(lambda i: es.pack_elites_device(self.mine[i].data_ptr(), self.E),
                        lambda i: es.inject_gathered_device(self.all[i].data_ptr(), self.world, self.rank, self.E))
 

@@ -33,7 +33,16 @@ def main():
     es.set_stream(stream.cuda_stream)
     es.set_target_audio(target)
     ex = pkg.island.IslandExchange(rank, world, elites, es.D, device, overlap=overlap)
+    reinit = len(sys.argv) > 8 and int(sys.argv[8]) != 0  # a run of 3 generations first, then init_population WITHOUT restart()
     with torch.cuda.stream(stream):
+        if reinit:
+            es.init_population(0)
+            for _ in range(3):
+                if fused:
+                    ex.generation(es)
+                else:
+                    es.execute_generations(1)
+                    ex.migrate_device(es)
         es.init_population(0)
         for _ in range(gens):
             if fused:

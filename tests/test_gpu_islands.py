@@ -57,10 +57,13 @@ def simulate(pkg, target, world, gens, elites, overlap, parents, offspring):
 # the fused-variation loop but is left to bench.py's rehearsal - the exchange code is the same
 # fused = 1: IslandExchange.generation (pack and inject inside the generation's sort kernel, what bench.py runs);
 # 4096 + 12288 takes the selection kernels, the small ones k_sort_small, 2048 + 6144 the tile sort + rank scatter
-@pytest.mark.parametrize("world,overlap,parents,offspring,fused", [
-    (2, 0, 2048, 6144, 0), (2, 1, 2048, 6144, 0), (3, 1, 96, 160, 0), (3, 0, 80, 176, 0),
-    (2, 0, 2048, 6144, 1), (2, 1, 2048, 6144, 1), (3, 1, 96, 160, 1), (3, 0, 80, 176, 1), (2, 1, 4096, 12288, 1), (3, 0, 4096, 12288, 1)])
-def test_migrate_device_across_processes_equals_host_exchange(tmp_path, pkg, O, world, overlap, parents, offspring, fused):
+# reinit = 1: the ranks first run three generations, then call init_population again WITHOUT IslandExchange.restart():
+# the exchange object must drop the old population's rows in flight by itself
+@pytest.mark.parametrize("world,overlap,parents,offspring,fused,reinit", [
+    (2, 0, 2048, 6144, 0, 0), (2, 1, 2048, 6144, 0, 0), (3, 1, 96, 160, 0, 0), (3, 0, 80, 176, 0, 0),
+    (2, 0, 2048, 6144, 1, 0), (2, 1, 2048, 6144, 1, 0), (3, 1, 96, 160, 1, 0), (3, 0, 80, 176, 1, 0), (2, 1, 4096, 12288, 1, 0),
+    (3, 0, 4096, 12288, 1, 0), (2, 1, 2048, 6144, 1, 1), (2, 1, 96, 160, 0, 1)])
+def test_migrate_device_across_processes_equals_host_exchange(tmp_path, pkg, O, world, overlap, parents, offspring, fused, reinit):
     gens, elites = 6, 16
     target = O.synth(0, [1450 / 3520, 3 / 8, 200 / 3520, 1.0], [0.0] * 4, PMAX, 1024)
     np.save(tmp_path / "target.npy", target)
@@ -70,7 +73,7 @@ def test_migrate_device_across_processes_equals_host_exchange(tmp_path, pkg, O, 
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_island_gpu_worker.py"), str(tmp_path),
-                                       str(gens), str(elites), str(overlap), str(parents), str(offspring), str(fused)], env=env,
+                                       str(gens), str(elites), str(overlap), str(parents), str(offspring), str(fused), str(reinit)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=600)
@@ -108,8 +111,12 @@ def test_one_device_group_is_the_plain_context(pkg, O):
     es.execute_generations(6)
     want = es.read_population()
     es.close()
-    for force in (False, True):
-        g = pkg.HipGroup([0], 16, 2048, 6144, pkg.capi.SYNTH_2OP, 10, None, PMAX, seed=0x5EED0001, force_rccl=force)
+    # (True, True, 1 | 2): the overlapped, host-gated schedule over RCCL - side-stream ncclAllGather, the island's thread
+    # waiting for `arrived` before the sort that takes the rows, with and without generations between two exchanges.
+    # One rank only: more than one DISTINCT device has not been available to these tests.
+    for force, overlap, interval in ((False, False, 1), (True, False, 1), (True, True, 1), (True, True, 2)):
+        g = pkg.HipGroup([0], 16, 2048, 6144, pkg.capi.SYNTH_2OP, 10, None, PMAX, seed=0x5EED0001, force_rccl=force,
+                         overlap=overlap, migration_interval=interval)
         assert g.size == 1 and g.uses_rccl == force
         g.set_target_audio(target)
         g.init_population(0)
@@ -118,7 +125,7 @@ def test_one_device_group_is_the_plain_context(pkg, O):
         g.synchronize()
         got = g.island(0).read_population()
         for x, y in zip(got, want):
-            assert np.array_equal(x, y), f"force_rccl={force}"
+            assert np.array_equal(x, y), f"force_rccl={force} overlap={overlap} interval={interval}"
         island, fit = g.best()
         assert island == 0 and fit == want[2].min()
         g.close()
