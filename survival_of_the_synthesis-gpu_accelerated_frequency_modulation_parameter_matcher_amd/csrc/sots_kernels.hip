@@ -807,6 +807,282 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
 }
 
 // ------------------------------------------------------------------------------------
+// Series voices: the OPERATORS in the lanes (k_synth_ol, round 4).
+//
+// k_synth gives an individual a lane, so a CU's share of 128 ... 256 individuals is two to four wavefronts - one per SIMD
+// at best, and a wavefront alone on its SIMD issues an instruction every ~4.5 cycles where two or more sharing it issue
+// one every ~2.3.  The cut kernels buy the second wavefront per SIMD with a wavefront per operator, LDS hand-overs and a
+// workgroup barrier per 8 samples (4-op, 128 per CU: 24 of 89 busy LDS cycles per sample and 28 us of barrier).
+// Here a LANE is one OPERATOR of one individual: a row of 16 lanes holds R = 8 / 4 / 4 individuals of the 2- / 3- / 4-operator
+// voice, operator s of individual i in lane R s + i (3 operators: R (s + 1) + i, the lanes in front make operator 0's constant
+// increment), so a wavefront carries 32 / 16 / 16 individuals and the CU's share is twice / four times as many wavefronts,
+// every one of them running ONE instruction stream in which all 64 lanes work:
+//   C  the lane's operator on its block of 8 samples: table read at the phase, phase += increment, wrap - the reference's
+//      operations (operator 0's second wrap adds 0 instead of W: it has only the first, Evolutionary_Strategy.hpp:383,418);
+//   A  the block read ONE TRIP AGO (its table values have landed): t * pm (for the last operator: the sample), + po, * c -
+//      the next operator's increments c * (t * mul + off), unfused, two samples per packed instruction;
+//   B  hand-over to the operator behind: ONE v_mov_b32_dpp row_shr:R per sample, no LDS, no barrier.  The bottom R lanes
+//      of a row have no source lane; DPP leaves such lanes alone, so operator 0's registers keep c * p1, the free-running
+//      operator's constant increment.
+// Operator s works on block k - 2 s in trip k (its increments were handed over in trip k - 1 from table values read in
+// trip k - 2).  The last operator's samples are spread over the G lanes of their individual (row_shl) so that every lane parks
+// 32 / G bytes per trip in the wavefront's tile with ONE LDS instruction (a write instruction costs the LDS the same 6-13 cycles
+// whether 16 lanes carry data or 64); rows = individuals, whole 128-byte lines leave every 32 samples as in k_synth.
+// Per sample and lane ~9 vector instructions + 1 LDS gather.  Every sample sees the reference's operations in its order:
+// bit-identical to k_synth and the oracle.
+// What it reaches (profiles/r04_experiments.md; tools/ubench/ol_loop.hip, lds_gather.hip): 87 cycles per sample for the
+// median wavefront and 97 for the slowest at configs[3]'s shard (k_synth<4OP, 1, ., 2, 3>: 112) - not the ~55 the LDS would
+// allow (a random 64-lane gather costs it 4.8-5.9 cycles, eight per sample): a wavefront of this instruction mix (v_cvt, v_pk_*,
+// three-operand integer minima, DPP moves at ~8 cycles each) needs 47-53 cycles per sample ALONE on its SIMD, a second one
+// adds only ~30 % (the SIMD issues oldest-first: 54 / 78 in isolation, the kernel ends with the younger), so only the
+// 4-operator voice at 65 ... 128 individuals per CU runs here (launch_synth).
+// ------------------------------------------------------------------------------------
+#ifndef SOTS_OL_ABL
+#define SOTS_OL_ABL 0
+#endif
+template <int OPS> struct OlShape {
+    static constexpr int G = OPS == 2 ? 2 : 4; // lanes per individual (3 operators: a fourth lane in front of operator 0 supplies its constant increment)
+    static constexpr int R = 16 / G;         // individuals per row of 16 lanes: 8 or 4
+    static constexpr int IPW = 4 * R;        // individuals per wavefront: 32 or 16
+    static constexpr int NI = IPW / 8;       // store instructions per flush (8 rows x 128 bytes each)
+};
+#ifdef SOTS_OL_PRIO
+#ifndef SOTS_OL_TURN
+#define SOTS_OL_TURN 32
+#endif
+constexpr uint32_t kOlTurn = SOTS_OL_TURN; // trips a wavefront keeps priority 1 before the next one sharing its SIMD gets it (a power of two)
+#endif
+constexpr int kOlTileRows = 256; // individuals per workgroup at most: 256 x 128 bytes of tiles = the 32 KiB beside the table
+template <int OPS> constexpr int ol_max_waves() { return kOlTileRows / OlShape<OPS>::IPW; } // 8 or 16
+
+template <int KIND>
+__global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void k_synth_ol(const float *__restrict__ values,
+                                                               const float *__restrict__ wavetable,
+                                                               float *__restrict__ audio, SynthParams sp,
+                                                               uint32_t p_len, uint32_t n, uint32_t pitch, Variation var)
+{
+    constexpr int OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
+    static_assert(VoiceShape<KIND>::J == 1, "series voices");
+    constexpr int G = OlShape<OPS>::G, R = OlShape<OPS>::R, IPW = OlShape<OPS>::IPW, NI = OlShape<OPS>::NI;
+    constexpr int U = 8, CH = kStageChunks;
+    constexpr int LAST = 2 * OPS - 1; // the block whose samples leave in trip k is k - LAST
+    __shared__ float tab[kWavetableSize];
+    __shared__ float4 stage_all[kOlTileRows * CH];
+    request_wavetable(tab, wavetable);
+    bool table_pending = true;
+    const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), waves = blockDim.x / kWave;
+    const uint32_t lr = lane & 15u, grp = lr / (uint32_t)R;        // this lane's place among the G lanes of its individual
+    const int s = (int)grp - (G - OPS);                            // ... i.e. its operator; -1: the 3-operator voice's constant source
+    const uint32_t li = (lane >> 4) * R + (lr - grp * R);          // ... of which individual of the wavefront
+    const uint32_t rows_per_block = waves * IPW;
+#ifdef SOTS_OL_PRIO
+    const uint32_t turn = wave / 4u, sharers = (waves + 3u) / 4u; // the wavefronts of a workgroup go to the SIMDs in turn: w, w + 4, ... share one
+#endif
+    float4 *__restrict__ stage = stage_all + wave * (IPW * CH);
+    // write side: the last operator's samples are spread over the G lanes of their individual first (row shifts), so that
+    // EVERY lane parks 32 / G bytes with one instruction; row = individual, chunk q in slot q ^ (row & 7)
+    const uint32_t l7 = li & 7u;
+    const uint32_t r8 = lane / CH, rch = lane % CH; // read side: lane = (row within a group of 8, chunk)
+    const float4 *__restrict__ rd = stage + r8 * CH + (rch ^ (r8 & 7u));
+    const uint32_t lane_off = r8 * pitch + 4u * rch;
+    uint32_t row_off[NI];
+#pragma unroll
+    for (int g = 0; g < NI; ++g) row_off[g] = (lane_off + (uint32_t)g * 8u * pitch) * 4u; // bytes; < 2^32: 32 rows of at most 8224 floats
+
+    const uint32_t first_base = blockIdx.x * rows_per_block;
+    for (uint32_t base = first_base; base < p_len; base += gridDim.x * rows_per_block) {
+        const uint32_t row0 = base + wave * IPW; // first row of this wavefront
+        const uint32_t ind = row0 + li < p_len ? row0 + li : p_len - 1u;
+        float p[D];
+        if (var.vin) {
+            // fused generation loop: the workgroup makes its individuals, a thread per gene (k_recombine_mutate's
+            // arithmetic), writes them to the other half and leaves the values in LDS for the lanes that need them
+            // (the tile area: nothing is parked there yet)
+            float *__restrict__ made = reinterpret_cast<float *>(stage_all);
+            if (base != first_base) __syncthreads(); // the previous tile's last lines have been read back
+            for (uint32_t t = threadIdx.x; t < rows_per_block * D; t += blockDim.x) {
+                const uint32_t i1 = base + t / D, g1 = t % D;
+                if (i1 < p_len) {
+                    const uint32_t src = recombine_source(i1, g1, var.pd);
+                    float x = var.vin[src], st = var.sin[src];
+                    mutate_gene(x, st, var.pd.gid_base + i1, g1, var.generation, var.pd, var.mc);
+                    var.vout[(size_t)i1 * D + g1] = x;
+                    var.sout[(size_t)i1 * D + g1] = st;
+                    made[t] = x;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < D; ++g) p[g] = made[(ind - base) * D + g];
+            __syncthreads(); // everybody has its genes: the tiles may be written
+        } else {
+#pragma unroll
+            for (int g = 0; g < D; ++g) p[g] = values[(size_t)ind * D + g];
+        }
+#pragma unroll
+        for (int g = 0; g < D; ++g) p[g] = sp.pmin[g] + p[g] * (sp.pmax[g] - sp.pmin[g]); // scaleParams, ocl_program.cl:297
+        // operator s hands (t * pm + po) * c to operator s + 1; the last operator's t * pm is the sample
+        float inc0c, pm = 0.0f, po = 0.0f;
+        if constexpr (KIND == SOTS_SYNTH_2OP) { // Evolutionary_Strategy.hpp:372-401
+            inc0c = c * p[0];
+            pm = s == 0 ? p[0] * p[1] : p[3], po = s == 0 ? p[2] : 0.0f;
+        } else { // series, :407-445 (the 4-operator voice adds one more modulator stage)
+            inc0c = c * p[1];
+#pragma unroll
+            for (int o = 0; o < OPS; ++o)
+                if (s == o) pm = p[2 * o] * p[2 * o + 1], po = o + 1 < OPS ? p[2 * o + 3] : 0.0f;
+        }
+        // 3 operators: the lane in front of operator 0 makes (t * 0 + p1) * c = c * p1 for it, sample after sample
+        if (G > OPS && s < 0) pm = 0.0f, po = p[1];
+        const float wlo = s <= 0 ? 0.0f : kWf; // operator 0 has the first wrap only
+        if (table_pending) {
+            wavetable_ready();
+            table_pending = false;
+        }
+
+        float pos = 0.0f;
+        float inc[U];  // this lane's increments for the block it works on next (operator 0: the constant, never overwritten)
+        float T[2][U]; // table values of the block of this trip's parity / of the trip before
+#pragma unroll
+        for (int u = 0; u < U; ++u) inc[u] = s == 0 ? inc0c : 0.0f, T[0][u] = 0.0f, T[1][u] = 0.0f;
+        float pend[NI][4];
+        float *__restrict__ pend_line = audio;
+        bool pending = false;
+        auto store_pending = [&]() {
+            if (!pending) return;
+            pending = false;
+#pragma unroll
+            for (int g = 0; g < NI; ++g) {
+                if (row0 + 8u * g + r8 >= p_len) continue;
+                asm volatile("" : "+v"(row_off[g]));
+                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(pend_line) + row_off[g]) = make_float4(pend[g][0], pend[g][1], pend[g][2], pend[g][3]);
+            }
+        };
+        const uint32_t nb = n / U;
+        // PHASE 1: the first trips (an operator idles, increments 0, until its first block arrives; samples leave from trip LAST),
+        // 0: the body, 2: the last trips (samples leave while their block exists)
+        auto trip = [&](auto q_tag, auto phase_tag, uint32_t k) {
+            constexpr int Q = decltype(q_tag)::value, PHASE = decltype(phase_tag)::value;
+            // C: this lane's operator on its block
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#if SOTS_OL_ABL & 1 // timing ablations (never in the shipped build; the audio is NOT valid): no table reads
+                T[Q][u] = pos * 1e-9f;
+#elif SOTS_OL_ABL & 16 // conflict-free table reads (no index arithmetic either)
+                T[Q][u] = tab[lane + 64 * u];
+#else
+                {
+                    // table[clamp((int)pos, 0, W-1)] (tab_at): v_cvt_u32_f32 saturates - negative and NaN give 0, as the
+                    // oracle's tab_at does - then one unsigned minimum; both cheaper to issue than the signed med3
+                    uint32_t ti;
+                    asm("v_cvt_u32_f32 %0, %1" : "=v"(ti) : "v"(pos));
+                    T[Q][u] = tab[min(ti, kWavetableSize - 1u)];
+                }
+#endif
+                pos += inc[u];
+#if !(SOTS_OL_ABL & 8) // 8: no wraps
+                const v2f_t bc = v2f_t{pos, pos} + v2f_t{-kWf, wlo};
+                pos = __uint_as_float(min(min(__float_as_uint(bc.x), __float_as_uint(bc.y)), __float_as_uint(pos)));
+#endif
+            }
+            // (nothing of A may move above this trip's table reads: it would wait for the reads of the trip before with none in
+            // flight behind them - the scheduler did, and every trip began with s_waitcnt lgkmcnt(0))
+            __builtin_amdgcn_sched_barrier(0);
+            // A: the block read one trip ago (its table values have landed): t * pm (the last operator's samples), + po, * c
+            v2f_t m[U / 2];
+#pragma unroll
+            for (int u = 0; u < U; u += 2) {
+                m[u / 2] = v2f_t{T[Q ^ 1][u], T[Q ^ 1][u + 1]} * pm;
+                const v2f_t o = (m[u / 2] + po) * c;
+                // B: to the operator behind (lanes R ... 15 of every row take from R lanes below; lanes 0 ... R-1 have no source lane
+                // and keep theirs: operator 0's constant)
+#if SOTS_OL_ABL & 2 // no lane shift
+                inc[u] = o.x, inc[u + 1] = o.y;
+#else
+                inc[u] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inc[u]), __float_as_int(o.x), 0x110 + R, 0xf, 0xf, false));
+                inc[u + 1] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inc[u + 1]), __float_as_int(o.y), 0x110 + R, 0xf, 0xf, false));
+#endif
+            }
+            if constexpr (PHASE == 1) {
+                if (s >= 1 && 2u * (uint32_t)s > k + 1u) { // this operator's first block has not arrived yet
+#pragma unroll
+                    for (int u = 0; u < U; ++u) inc[u] = 0.0f;
+                }
+            }
+            // the samples of block k - LAST leave
+#if SOTS_OL_ABL & 4 // no tile, no stores
+            if (pm == 12345.678f && m[0].x == 1.0f && m[1].y == 2.0f && m[2].x == 5.0f && m[3].y == 0.1f) {
+#else
+            if (PHASE == 0 || (k >= (uint32_t)LAST && k - (uint32_t)LAST < nb)) {
+#endif
+                const uint32_t ip = (k - (uint32_t)LAST) * U;
+                store_pending(); // the lines read back one trip ago
+                const uint32_t c0 = (ip >> 2) & (CH - 1);
+                // the 8 samples sit in the last operator's lanes (the top R lanes of every row): lane group g of the individual takes
+                // samples 8 g / G ... from them (row_shl: a lane reads the lane n above it; lanes without a source keep theirs), then
+                // all 64 lanes write (a write instruction costs the LDS the same whether 16 lanes carry data or 64: 26 -> 6 cycles per sample and CU)
+                auto shl = [&](float keep, float src, auto n_tag) {
+                    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x100 + decltype(n_tag)::value, 0xf, 0xf, false));
+                };
+                if constexpr (G == 4) {
+                    v2f_t w = m[3];
+                    w.x = shl(w.x, m[2].x, ic<R>{}), w.y = shl(w.y, m[2].y, ic<R>{});
+                    w.x = shl(w.x, m[1].x, ic<2 * R>{}), w.y = shl(w.y, m[1].y, ic<2 * R>{});
+                    w.x = shl(w.x, m[0].x, ic<3 * R>{}), w.y = shl(w.y, m[0].y, ic<3 * R>{});
+                    float2 *__restrict__ wr2 = reinterpret_cast<float2 *>(stage + li * CH);
+                    wr2[((c0 + (grp >> 1)) ^ l7) * 2u + (grp & 1u)] = make_float2(w.x, w.y);
+                } else {
+                    float4 w = make_float4(m[2].x, m[2].y, m[3].x, m[3].y);
+                    w.x = shl(w.x, m[0].x, ic<R>{}), w.y = shl(w.y, m[0].y, ic<R>{}), w.z = shl(w.z, m[1].x, ic<R>{}), w.w = shl(w.w, m[1].y, ic<R>{});
+                    stage[li * CH + ((c0 + grp) ^ l7)] = w;
+                }
+                if (c0 == CH - U / 4) { // 32 samples parked: the tile is read back transposed (LDS works in order) and stored in the next trip
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int g = 0; g < NI; ++g) {
+                        const float4 q = rd[g * (8 * CH)];
+                        pend[g][0] = q.x, pend[g][1] = q.y, pend[g][2] = q.z, pend[g][3] = q.w;
+                    }
+                    pend_line = audio + (size_t)row0 * pitch + (ip + U - 4 * CH); // wavefront-uniform
+                    pending = true;
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+        };
+        constexpr uint32_t K0 = 2 * OPS; // first trip (even) in which every operator works and samples leave
+        SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave); // (diagnostic builds: this wavefront's cycles over all trips)
+        for (uint32_t k = 0; k < K0; k += 2) {
+            trip(ic<0>{}, ic<1>{}, k);
+            trip(ic<1>{}, ic<1>{}, k + 1);
+        }
+        for (uint32_t k = K0; k < nb; k += 2) {
+#ifdef SOTS_OL_PRIO // (experiment, off: it evens the wavefronts out at the SLOW end - 75 / 92 against 65 / 94 cycles per sample)
+            // The SIMD issues for its OLDEST wavefront first: of two that share it the older runs as if alone (54 cycles per
+            // sample in isolation) and the younger takes what is left (78) - and the kernel ends with the younger.  The
+            // wavefronts that share a SIMD (w, w + 4, ... of the workgroup) take turns at priority 1, kOlTurn trips each (a
+            // turn per trip costs more than it brings: the taken branch around s_setprio's immediate is ~100 cycles).
+            if ((k & (kOlTurn - 1u)) == 0u) {
+                const uint32_t mine = __builtin_amdgcn_readfirstlane(((k / kOlTurn) % sharers) == turn ? 1u : 0u);
+                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n\ts_branch 2f\n1:\ts_setprio 0\n2:" ::"s"(mine));
+            }
+#endif
+            trip(ic<0>{}, ic<0>{}, k);
+            trip(ic<1>{}, ic<0>{}, k + 1);
+        }
+        for (uint32_t k = nb; k < nb + K0; k += 2) { // the last block leaves in trip nb - 1 + LAST
+            trip(ic<0>{}, ic<2>{}, k);
+            trip(ic<1>{}, ic<2>{}, k + 1);
+        }
+        store_pending();
+    }
+    if (table_pending) wavetable_ready(); // a workgroup without a tile must not end with copies in flight
+}
+
+// ------------------------------------------------------------------------------------
 // SMALL populations (a few individuals per CU), every voice: the time axis in the lanes.
 //
 // k_synth above puts an individual in a lane and pays its ten to twenty vector instructions per sample and operator whether
@@ -2873,6 +3149,9 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 #ifndef SOTS_TP_2OP_MAX
 #define SOTS_TP_2OP_MAX 16
 #endif
+#ifndef SOTS_OL_MIN_SHARE
+#define SOTS_OL_MIN_SHARE 48
+#endif
 bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
 {
 #ifdef SOTS_SYNTH_NO_TP
@@ -2911,6 +3190,35 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         }
         return hipGetLastError();
     }
+    // The 4-operator voice at 65 ... 128 individuals per CU (BASELINE configs[3]'s shard): the operators in the lanes (k_synth_ol) -
+    // every wavefront carries 16 individuals, eight wavefronts per CU without hand-overs or barriers: 180 against 189 us, 337 against
+    // 357 us per generation in a same-box A/B.  Everywhere else the kernels above measure faster (2-op P = 65 536: 51 against 55 us;
+    // 3-op N = 2048: 137 against 170; 4-op at 256 per CU: 327 against 343; profiles/r04_experiments.md), so `SOTS_OL_ALL` is an
+    // experiment switch.
+#ifndef SOTS_SYNTH_NO_OL
+#ifdef SOTS_OL_ALL
+    const bool use_ol = allow_cut && kind != SOTS_SYNTH_TRIPLE_PAR && share >= (uint32_t)SOTS_OL_MIN_SHARE;
+#else
+    const bool use_ol = allow_cut && kind == SOTS_SYNTH_4OP_SERIES && share > 64u && share <= 128u;
+#endif
+    if (use_ol) {
+        auto launch_ol = [&](auto kind_tag) {
+            constexpr int K = decltype(kind_tag)::value, OPS = VoiceShape<K>::OPS, IPW = OlShape<OPS>::IPW;
+            constexpr uint32_t max_rows = ol_max_waves<OPS>() * IPW;
+            uint32_t rows = (share + IPW - 1) / IPW * IPW;
+            rows = rows > max_rows ? max_rows : rows;
+            uint32_t grid = (p + rows - 1) / rows;
+            grid = grid > cus ? cus : grid; // larger populations: a workgroup takes several tiles
+            k_synth_ol<K><<<grid, rows / IPW * kWave, 0, st>>>(values, wavetable, audio, sp, p, n, pitch, var);
+        };
+        switch (kind) {
+        case SOTS_SYNTH_2OP: launch_ol(ic<SOTS_SYNTH_2OP>{}); break;
+        case SOTS_SYNTH_3OP_SERIES: launch_ol(ic<SOTS_SYNTH_3OP_SERIES>{}); break;
+        default: launch_ol(ic<SOTS_SYNTH_4OP_SERIES>{}); break;
+        }
+        return hipGetLastError();
+    }
+#endif
     uint32_t waves = (share + kWave - 1) / kWave;
     waves = waves < 1 ? 1 : waves > (uint32_t)kSynthWaves ? (uint32_t)kSynthWaves : waves;
     const bool cut = allow_cut && waves <= 2 && kind != SOTS_SYNTH_TRIPLE_PAR;

@@ -173,6 +173,55 @@ def test_synthesise_two_op_large_population_uses_lane_per_individual_kernel(pkg,
     es.close()
 
 
+# k_synth_ol (round 4): the 4-operator voice at 65 ... 128 individuals per CU (BASELINE configs[3]'s shard) runs with the OPERATORS
+# in the lanes - a row of 16 lanes holds 4 individuals, hand-over by DPP row shifts, no LDS links, no barriers.
+# Sizes: configs[3]'s shard; the same with a partly filled last workgroup; a ragged population (recombination blocks of 1) in wild
+# parameter boxes (negative and beyond-table increments: operator 0 has the first wrap only, the index clamp acts on both sides);
+# the other voices and sizes (kernels of rounds 1-3; with -DSOTS_OL_ALL the same kernel for the 2- and 3-operator voices and for
+# populations of several tiles per workgroup) keep their cases.
+@pytest.mark.parametrize("kind,log2n,parents,offspring,wild", [
+    (3, 12, 8192, 24576, False), (3, 9, 8192, 24416, False), (3, 9, 5000, 15011, True), (3, 10, 4352, 13056, False),
+    (0, 10, 4096, 12288, False), (0, 9, 3333, 9987, True), (0, 10, 16640, 49920 + 32 * 700, False),
+    (1, 11, 3072, 9216, False), (1, 9, 3100, 9311, True), (1, 9, 20000, 50016, False),
+    (3, 9, 3111, 9332, True), (3, 9, 20000, 60032, False)])
+def test_synthesise_operators_in_the_lanes_bitexact(pkg, O, kind, log2n, parents, offspring, wild):
+    pmin, pmax = WILD[kind] if wild else (None, PMAX[kind])
+    block = 32 if (parents + offspring) % 32 == 0 else 1
+    es, _ = make_pair(pkg, O, parents, offspring, kind, log2n, block=block, pmin=pmin, pmax=pmax)
+    es.init_population(0)
+    v, s, _ = es.read_population()
+    _, tv = target_audio(O, kind, es.N)
+    v[0], v[1], v[2], v[es.P - 1] = tv, 0.0, 1.0, tv
+    es.write_population(v, s, None)
+    es.synthesise()
+    audio = es.read_audio()
+    rng = np.random.default_rng(41 + kind)
+    share = -(-es.P // 256)
+    rows = np.unique(np.concatenate([np.arange(0, 70), np.arange(es.P - 70, es.P), np.arange(share - 40, share + 40) % es.P,
+                                     np.arange(255, 265) * share % es.P, rng.choice(es.P, 120, replace=False)]))
+    lo = [0.0] * es.D if pmin is None else pmin
+    for r in rows:
+        assert np.array_equal(audio[r], O.synth(kind, v[r], lo, pmax, es.N)), f"row {r}"
+    es.close()
+    if wild:
+        return
+    # the fused loop (the workgroup makes its individuals, a thread per gene, where the variation is folded in): same audio
+    # and same population as the separate stages
+    a, _ = make_pair(pkg, O, parents, offspring, kind, log2n, block=block)
+    b, _ = make_pair(pkg, O, parents, offspring, kind, log2n, block=block)
+    tgt, _ = target_audio(O, kind, a.N)
+    for e in (a, b):
+        e.set_target_audio(tgt)
+        e.init_population(0)
+    a.execute_generations(1)
+    b.recombine(); b.mutate(); b.synthesise()
+    assert np.array_equal(a.read_audio(), b.read_audio())
+    b.window(); b.fft(); b.fitness(); b.sort(); b.rotate()
+    for x, y in zip(a.read_population(), b.read_population()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_synthesise_nonzero_param_min(pkg, O):
     pmin = [100.0, 0.5, 50.0, 0.1]
     es, ref = make_pair(pkg, O, 32, 32, 0, 10, pmin=pmin)

@@ -52,6 +52,66 @@ __global__ __launch_bounds__(1024) void k(const uint32_t *addr, float *out, unsi
     if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+// Gathers BESIDE vector work: per ds_read_b32 (random pattern) V independent v_fma_f32 of the same wavefront.  If the LDS and the
+// vector unit overlap, a step costs max(gather, V x issue); if a gather in flight holds up the wavefront's (or the SIMD's)
+// vector issue, it costs their sum.
+template <int V>
+__global__ __launch_bounds__(1024) void k_mix(const uint32_t *addr, float *out, unsigned long long *cyc, int iters)
+{
+    extern __shared__ float tab[];
+    for (int i = threadIdx.x; i < 32768; i += blockDim.x) tab[i] = (float)i;
+    uint32_t a[16];
+    const int lane = threadIdx.x & 63;
+    for (int r = 0; r < 16; ++r) a[r] = addr[r * 64 + lane];
+    float f[8];
+    for (int i = 0; i < 8; ++i) f[i] = lane * 0.001f + i;
+    __syncthreads();
+    float s = 0.f;
+    float v[2][16];
+    for (int r = 0; r < 16; ++r) v[0][r] = v[1][r] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) f[(r * V + j) & 7] = __builtin_fmaf(f[(r * V + j) & 7], 0.999f, 0.001f);
+                asm volatile("ds_read_b32 %0, %1" : "=v"(v[h][r]) : "v"(a[r]));
+            }
+            // the values read in the PREVIOUS half are consumed now (a whole half later: their latency is covered)
+            if (h == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); // (never more than 16 outstanding anyway)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[h ^ 1][r]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[0][r] + v[1][r];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; ++i) s += f[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int V>
+void run_mix(const uint32_t *d_addr, float *out, unsigned long long *cyc)
+{
+    hipFuncSetAttribute((const void *)k_mix<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int iters = 2000;
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        const int threads = 256 * wps;
+        for (int rep = 0; rep < 2; ++rep) k_mix<V><<<256, threads, 131072>>>(d_addr, out, cyc, iters);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
+        std::vector<unsigned long long> hc(256 * threads / 64);
+        hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost);
+        double sum = 0; for (auto v : hc) sum += v;
+        const double per_step = sum / hc.size() / ((double)iters * 16); // one gather + V fma, as one wave sees it
+        printf("mix V=%2d   waves/SIMD=%d  cycles per (gather + V fma) per wave=%6.2f  per SIMD=%6.2f  per CU and gather=%6.2f\n", V, wps,
+               per_step, per_step / wps, per_step / (4 * wps));
+    }
+}
+
 int main()
 {
     uint32_t *d_addr; float *out; unsigned long long *cyc;
@@ -98,5 +158,16 @@ int main()
                    names[pat], wps, per_wave, 4 * wps, per_wave / (4 * wps));
         }
     }
+    // random pattern again for the mixes
+    {
+        std::vector<uint32_t> h(16 * 64);
+        for (auto &w : h) w = (rng() % 32768) * 4;
+        hipMemcpy(d_addr, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    }
+    run_mix<0>(d_addr, out, cyc);
+    run_mix<2>(d_addr, out, cyc);
+    run_mix<4>(d_addr, out, cyc);
+    run_mix<8>(d_addr, out, cyc);
+    run_mix<12>(d_addr, out, cyc);
     return 0;
 }
