@@ -113,32 +113,37 @@ def make_target(pkg, voice, log2n, device):
 
 def cpu_baseline(voice, log2n, target_audio, budget_s=10.0, max_threads=16):
     """The CPU oracle (oracle/sots_oracle.c, a single-threaded port of the reference's
-    Evolutionary_Strategy_CPU path) timed on this host on a bounded sample of the workload.
-    Both legs stop on the clock, so the sample size adapts to the host."""
+    Evolutionary_Strategy_CPU path) timed on this host on a bounded sample of the workload: the three population
+    sizes of BASELINE.md section 3 (P = 64 - BASELINE configs[0] -, 1024, 4096; the workload's voice and N), every
+    leg stopped by the clock, so the sample adapts to the host.  `value` is the P = 4096 leg on one core."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP threads sleep instead of spinning
     from oracle import oracle as O
-    parents, offspring = 512, 1536
     kind = {"2op": O.SYNTH_2OP, "3op_series": O.SYNTH_3OP_SERIES, "4op_series": O.SYNTH_4OP_SERIES,
             "triple_parallel": O.SYNTH_TRIPLE_PAR}[voice]
-    ref = O.OracleES(parents, offspring, kind, log2n, None, VOICES[voice][0], seed=0x5EED0001, recomb_block=32)
-    ref.set_target_audio(target_audio)
-    ref.init_population(0)
-    p = parents + offspring
 
-    def timed(budget):
+    def timed(ref, budget):
         ref.generation()  # warm
         gens, t0 = 0, time.perf_counter()
         while True:
             ref.generation()
             gens += 1
             dt = time.perf_counter() - t0
-            if dt >= budget or gens >= 5000:
+            if dt >= budget or gens >= 20000:
                 return gens, dt
 
-    gens, dt = timed(budget_s)
-    out = {"value": p * gens / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
-           "sample": f"pop={p} x {gens} generations, {voice} FM, N={1 << log2n}, fp64 built-in FFT "
-                     f"(FFTW unavailable), {dt:.1f} s on 1 core"}
+    sizes, ref = [], None
+    for parents, offspring, share in ((16, 48, 0.25), (256, 768, 0.25), (1024, 3072, 0.5)):
+        ref = O.OracleES(parents, offspring, kind, log2n, None, VOICES[voice][0], seed=0x5EED0001, recomb_block=min(32, parents))
+        ref.set_target_audio(target_audio)
+        ref.init_population(0)
+        p = parents + offspring
+        gens, dt = timed(ref, share * budget_s)
+        sizes.append({"pop": p, "value": p * gens / dt, "generations": gens, "seconds": dt})
+    big = sizes[-1]
+    out = {"value": big["value"], "unit": "candidates/s", "cores": 1, "kind": "port",
+           "sample": f"pop={big['pop']} x {big['generations']} generations, {voice} FM, N={1 << log2n}, fp64 built-in FFT "
+                     f"(FFTW unavailable), {big['seconds']:.1f} s on 1 core; `sizes`: the same at pop = 64 (BASELINE configs[0]) and 1024",
+           "sizes": sizes}
     # SURVEY 8(d): the reference's CPU path is single-threaded (the faithful baseline above); additionally
     # the evaluation loop (synthesis + FFT + fitness, independent per individual) on the CPUs this process
     # may run on (its affinity mask), at most --cpu-threads of them
@@ -150,11 +155,11 @@ def cpu_baseline(voice, log2n, target_audio, budget_s=10.0, max_threads=16):
     if cores > 1:
         O.set_threads(cores)
         try:
-            gens_mt, dt_mt = timed(0.5 * budget_s)
+            gens_mt, dt_mt = timed(ref, 0.5 * budget_s)
         finally:
             O.set_threads(1)
-        out["all_cores"] = {"value": p * gens_mt / dt_mt, "unit": "candidates/s", "cores": cores,
-                            "sample": f"same workload, evaluation loop under OpenMP on {cores} threads "
+        out["all_cores"] = {"value": big["pop"] * gens_mt / dt_mt, "unit": "candidates/s", "cores": cores,
+                            "sample": f"pop={big['pop']}, evaluation loop under OpenMP on {cores} threads "
                                       f"(affinity mask: {allowed} CPUs, --cpu-threads {max_threads}; variation and sort stay "
                                       f"serial), {gens_mt} generations in {dt_mt:.1f} s"}
     return out

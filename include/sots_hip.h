@@ -94,7 +94,7 @@ typedef struct sots_config {
     uint32_t num_parents;       /* es_args.pop.numParents */
     uint32_t num_offspring;     /* es_args.pop.numOffspring */
     uint32_t num_dimensions;    /* es_args.pop.numDimensions */
-    uint32_t audio_length_log2; /* es_args.audioLengthLog2, 9..13 */
+    uint32_t audio_length_log2; /* es_args.audioLengthLog2, 8..15 (N = 256 ... 32768; main.cpp:90 takes any) */
     uint32_t num_generations;   /* es_args.numGenerations */
     uint32_t synth_kind;        /* enum sots_synth_kind */
     uint32_t workgroup_size;    /* workgroupX: the recombination block (WRKGRPSIZE in ocl_program.cl:86-148) */

@@ -227,7 +227,7 @@ typedef struct {
     double *zr, *zi;   /* work, n/2 */
 } rfft_plan;
 
-#define MAX_PLANS 8
+#define MAX_PLANS 16
 static rfft_plan g_plans[MAX_PLANS];
 static int g_nplans = 0;
 

@@ -328,8 +328,8 @@ int sots_create(const sots_config *cfg, sots_ctx **out)
     if (cfg->num_dimensions != d)
         return fail(nullptr, SOTS_ERR_INVALID, "synth_kind %u needs numDimensions %u, got %u", cfg->synth_kind,
                     d, cfg->num_dimensions);
-    if (cfg->audio_length_log2 < 9 || cfg->audio_length_log2 > 13)
-        return fail(nullptr, SOTS_ERR_INVALID, "audioLengthLog2 %u outside 9..13", cfg->audio_length_log2);
+    if (cfg->audio_length_log2 < 8 || cfg->audio_length_log2 > 15)
+        return fail(nullptr, SOTS_ERR_INVALID, "audioLengthLog2 %u outside 8..15", cfg->audio_length_log2);
     const uint64_t p64 = (uint64_t)cfg->num_parents + cfg->num_offspring;
     if (cfg->num_parents == 0 || p64 < 2 || p64 > (1ull << 26))
         return fail(nullptr, SOTS_ERR_INVALID, "population %llu (parents %u) not supported",

@@ -2833,7 +2833,7 @@ __global__ __launch_bounds__((WG * kWave)) void k_fft_x(const float *__restrict_
                                                                    uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch,
                                                                    const float *__restrict__ image)
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = WG;
+    constexpr int N = 1 << LOG2N, M = N / 2, E = x_points<LOG2N>(), EB = (E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = WG;
     constexpr int S2 = E + 2, S1 = E + 4; // lane strides of the float2 / float tables (16-byte reads, spread over the banks)
     __shared__ __attribute__((aligned(16))) float xt_s[x_table_floats<LOG2N>()]; // (the variants without window or target leave theirs unused)
     float2 *const tw2_s = reinterpret_cast<float2 *>(xt_s), *const tws_s = tw2_s + kWave * S2, *const win_s = tws_s + kWave * S2;
@@ -2846,9 +2846,8 @@ __global__ __launch_bounds__((WG * kWave)) void k_fft_x(const float *__restrict_
     const unsigned long long xs_begin = __builtin_amdgcn_s_memrealtime(), xs_begin_clk = __builtin_amdgcn_s_memtime();
     unsigned long long xs_wait = 0, xs_rows = 0, xs_split = 0;
 #endif
-    if (MODE == 1 && WIN && image != nullptr) {
+    if (MODE == 1 && WIN && image != nullptr) { // (launch_x_tables makes images only where the tables are whole 1 KiB pieces: N >= 2048)
         typedef __attribute__((address_space(3))) void *lds_ptr_t;
-        static_assert(x_table_floats<LOG2N>() % 256 == 0, "whole 1 KiB pieces");
         for (uint32_t ch = wave; ch < (uint32_t)x_table_floats<LOG2N>() / 256u; ch += W)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(image) + ch * 256u + lane * 4u, (lds_ptr_t)(xt_s + ch * 256u), 16, 0, 0);
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): this wavefront's pieces have landed (the barrier below covers the others')
@@ -3027,12 +3026,109 @@ __global__ __launch_bounds__((WG * kWave)) void k_fft_x(const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Rows of N = 16384 and 32768 samples (round 4: the reference takes any audioLengthLog2, main.cpp:90, and renders 2^14
+// samples of its best match, main.cpp:273): a WORKGROUP per row.  Such a row is 128 or 256 registers per lane of one
+// wavefront, more than k_fft_x can hold; here its M = N / 2 complex points live in LDS (64 or 128 KiB), 512 threads run an
+// in-place radix-2 DIF (natural order in, bit-reversed out) with one workgroup barrier per stage, and the real-input split
+// reads Z[k] and Z[M - k] at their bit-reversed places.  Coverage, not speed: nothing of BASELINE's configs runs here.
+//   MODE 0: spectrum row (bins 0 .. M) to memory; MODE 1: squared error against the target, bins 0 .. M-1
+//   (Evolutionary_Strategy_CPU.hpp:235).  Thread t takes bins t, t + 512, ... in rising order, the wavefront totals are added
+//   in wavefront order; k_fitness_big repeats map and order on a materialised row (bit-identical sums).
+// ------------------------------------------------------------------------------------
+constexpr int kBigThreads = 512;
+template <int LOG2N> constexpr bool big_applies() { return LOG2N == 14 || LOG2N == 15; }
+
+__device__ __forceinline__ float big_block_sum(float acc, float *__restrict__ red)
+{
+    acc = wave_sum(acc);
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    float total = 0.0f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kBigThreads / kWave; ++w) total += red[w];
+    return total; // (thread 0's)
+}
+
+template <int LOG2N, int MODE, bool WIN>
+__global__ __launch_bounds__(kBigThreads) void k_fft_big(const float *__restrict__ audio, float *__restrict__ spectrum,
+                                                         const float *__restrict__ target, float *__restrict__ fitness,
+                                                         const float2 *__restrict__ tw, const float *__restrict__ window,
+                                                         uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch)
+{
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2, LM = LOG2N - 1, T = kBigThreads;
+    extern __shared__ float2 big_z[]; // M complex points (the launch asks for M * 8 + 64 bytes)
+    float *__restrict__ red = reinterpret_cast<float *>(big_z + M);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t row = blockIdx.x; row < p_len; row += gridDim.x) {
+        const float2 *__restrict__ in = reinterpret_cast<const float2 *>(audio + (size_t)row * pitch);
+        for (uint32_t i = t; i < M; i += T) {
+            float2 v = in[i];
+            if constexpr (WIN) {
+                const float2 w = reinterpret_cast<const float2 *>(window)[i];
+                v.x *= w.x, v.y *= w.y;
+            }
+            big_z[i] = v;
+        }
+        __syncthreads();
+        // in-place radix-2 DIF: stage s pairs i and i + half, half = M >> (s + 1); the difference takes W_{2 half}^{j} = W_N^{j N / (2 half)}
+        for (uint32_t st = 0; st < LM; ++st) {
+            const uint32_t half = M >> (st + 1), tw_step = N / (2u * half);
+            for (uint32_t b = t; b < M / 2; b += T) {
+                const uint32_t j = b & (half - 1), i0 = ((b - j) << 1) + j, i1 = i0 + half;
+                const float2 a = big_z[i0], c = big_z[i1];
+                big_z[i0] = cadd(a, c);
+                const float2 d = csub(a, c);
+                big_z[i1] = j == 0 ? d : cmul(d, tw[j * tw_step]);
+            }
+            __syncthreads();
+        }
+        // Z[k] now lies at bitrev(k).  X[k] = (Z[k] + conj Z[M-k]) / 2 + W_N^k (-i) (Z[k] - conj Z[M-k]) / 2, Z[M] read as Z[0]
+        auto bin = [&](uint32_t k) -> float2 {
+            const uint32_t km = (M - k) & (M - 1);
+            const float2 a = big_z[__brev(k) >> (32 - LM)], bz = big_z[__brev(km) >> (32 - LM)];
+            const float2 ee = make_float2(0.5f * (a.x + bz.x), 0.5f * (a.y - bz.y)), dd = make_float2(0.5f * (a.x - bz.x), 0.5f * (a.y + bz.y));
+            const float2 o = make_float2(dd.y, -dd.x); // -i dd
+            const float2 w = tw[k];
+            return make_float2(ee.x + (o.x * w.x - o.y * w.y), ee.y + (o.x * w.y + o.y * w.x));
+        };
+        if constexpr (MODE == 0) {
+            float2 *__restrict__ dst = reinterpret_cast<float2 *>(spectrum + (size_t)row * (N + 8));
+            for (uint32_t k = t; k < M; k += T) dst[k] = bin(k);
+            if (t == 0) dst[M] = make_float2(big_z[0].x - big_z[0].y, 0.0f); // the Nyquist bin X[M] = Re Z0 - Im Z0
+        } else {
+            float acc = 0.0f;
+            for (uint32_t k = t; k < M; k += T) acc += bin_error(bin(k), target[k], inv_n * inv_wf);
+            const float total = big_block_sum(acc, red);
+            if (t == 0) fitness[row] = total;
+        }
+        __syncthreads(); // the next row overwrites big_z and red
+    }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(kBigThreads) void k_fitness_big(const float *__restrict__ spectrum, const float *__restrict__ target,
+                                                             float *__restrict__ fitness, uint32_t p_len, float inv_n, float inv_wf)
+{
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2, T = kBigThreads;
+    __shared__ float red[kBigThreads / kWave];
+    for (uint32_t row = blockIdx.x; row < p_len; row += gridDim.x) {
+        const float2 *__restrict__ src = reinterpret_cast<const float2 *>(spectrum + (size_t)row * (N + 8));
+        float acc = 0.0f;
+        for (uint32_t k = threadIdx.x; k < M; k += T) acc += bin_error(src[k], target[k], inv_n * inv_wf);
+        const float total = big_block_sum(acc, red);
+        if (threadIdx.x == 0) fitness[row] = total;
+        __syncthreads();
+    }
+}
+
 // fitnessPopulation on materialised rows with k_fft_x's bin -> (lane, register) map and summation order
 template <int LOG2N>
 __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fitness_x(const float *__restrict__ spectrum, const float *__restrict__ target,
                                                                        float *__restrict__ fitness, uint32_t p_len, float inv_n, float inv_wf)
 {
-    constexpr int N = 1 << LOG2N, E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N>();
+    constexpr int N = 1 << LOG2N, E = x_points<LOG2N>(), EB = (E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), W = x_waves<LOG2N>();
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t pp = __brev(lane) >> 26;
     for (uint32_t row = blockIdx.x * W + wave; row < p_len; row += gridDim.x * W) {
@@ -3054,7 +3150,7 @@ template <int LOG2N>
 __global__ __launch_bounds__(256) void k_x_tables(float *__restrict__ image, const float2 *__restrict__ tw,
                                                   const float *__restrict__ window, const float *__restrict__ target)
 {
-    constexpr int E = x_points<LOG2N>(), EB = (E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), S2 = E + 2, S1 = E + 4;
+    constexpr int E = x_points<LOG2N>(), EB = (E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6), S2 = E + 2, S1 = E + 4;
     float2 *const tw2_s = reinterpret_cast<float2 *>(image), *const tws_s = tw2_s + kWave * S2, *const win_s = tws_s + kWave * S2;
     float *const tgt_s = reinterpret_cast<float *>(win_s + kWave * S2);
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < (uint32_t)(kWave * E); e += gridDim.x * blockDim.x) {
@@ -3321,15 +3417,38 @@ static uint32_t resident_grid(K kernel, int threads, uint32_t items, uint32_t nu
 #ifndef SOTS_X_MIN
 #define SOTS_X_MIN 11
 #endif
-static bool x_from(uint32_t log2n) { return log2n >= SOTS_X_MIN && log2n <= 13; }
+// ... and N = 256 (round 4): two complex points per lane, the same kernel (k_fft's radix-4 / radix-8 passes need four or eight)
+static bool x_from(uint32_t log2n) { return log2n == 8 || (log2n >= SOTS_X_MIN && log2n <= 13); }
 #define SOTS_DISPATCH_X(log2n, CALL)      \
     switch (log2n) {                      \
+    case 8: { CALL(8); break; }           \
     case 10: { CALL(10); break; }         \
     case 11: { CALL(11); break; }         \
     case 12: { CALL(12); break; }         \
     case 13: { CALL(13); break; }         \
     default: return hipErrorInvalidValue; \
     }
+static bool big_from(uint32_t log2n) { return log2n == 14 || log2n == 15; }
+// a workgroup per row: as many workgroups as rows, at most four per CU (they loop)
+template <int L, int MODE, bool WIN>
+static hipError_t launch_fft_big(hipStream_t st, uint32_t p, uint32_t num_cus, const float *audio, float *spectrum, const float *target,
+                                 float *fitness, const float2 *tw, const float *window, float inv_n, float inv_wf, uint32_t pitch)
+{
+    const uint32_t cus = num_cus ? num_cus : 256u, grid = p < 4u * cus ? p : 4u * cus;
+    const size_t lds = ((size_t)(1u << L) / 2u) * sizeof(float2) + 64u;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_big<L, MODE, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_fft_big<L, MODE, WIN><<<grid, kBigThreads, lds, st>>>(audio, spectrum, target, fitness, tw, window, p, inv_n, inv_wf, pitch);
+    return hipGetLastError();
+}
+template <int L>
+static hipError_t launch_fitness_big(hipStream_t st, uint32_t p, uint32_t num_cus, const float *spectrum, const float *target, float *fitness,
+                                     float inv_n, float inv_wf)
+{
+    const uint32_t cus = num_cus ? num_cus : 256u, grid = p < 4u * cus ? p : 4u * cus;
+    k_fitness_big<L><<<grid, kBigThreads, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf);
+    return hipGetLastError();
+}
 #define SOTS_X_GRID(K, L, MODE) resident_grid(K, x_waves<L, MODE>() * kWave, (p + x_waves<L, MODE>() - 1) / x_waves<L, MODE>(), num_cus, &occ_x[L])
 
 // N = 1024 from one row per resident wavefront (P >= 12 x CUs): one workgroup of twelve wavefronts per CU, rows dealt as
@@ -3351,6 +3470,10 @@ hipError_t launch_fft(hipStream_t st, const float *audio, float *spectrum, const
                       uint32_t p, uint32_t log2n, uint32_t pitch, uint32_t num_cus, OccCache *oc)
 {
     int *occ = oc->fft;
+    if (big_from(log2n)) {
+        if (log2n == 14) return launch_fft_big<14, 0, false>(st, p, num_cus, audio, spectrum, nullptr, nullptr, twiddle, nullptr, 0.f, 0.f, pitch);
+        return launch_fft_big<15, 0, false>(st, p, num_cus, audio, spectrum, nullptr, nullptr, twiddle, nullptr, 0.f, 0.f, pitch);
+    }
     if (fft_wide(p, log2n, num_cus) && !x_from(log2n)) {
         constexpr int W = fft_wide_waves<10>();
         k_fft<10, 0, false, W><<<SOTS_WIDE_GRID((k_fft<10, 0, false, W>), 0), W * kWave, 0, st>>>(audio, spectrum, nullptr, nullptr, twiddle, nullptr, p, 0.f, 0.f, pitch);
@@ -3373,6 +3496,10 @@ hipError_t launch_fitness(hipStream_t st, const float *spectrum, const float *ta
                           uint32_t p, uint32_t log2n, float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
     int *occ = oc->fitness;
+    if (big_from(log2n)) {
+        if (log2n == 14) return launch_fitness_big<14>(st, p, num_cus, spectrum, target, fitness, inv_n, inv_wf);
+        return launch_fitness_big<15>(st, p, num_cus, spectrum, target, fitness, inv_n, inv_wf);
+    }
     if (x_from(log2n)) {
         int *occ_x = oc->x_fitness;
 #define CALL(L) k_fitness_x<L><<<SOTS_X_GRID(k_fitness_x<L>, L, 1), x_waves<L>() * kWave, 0, st>>>(spectrum, target, fitness, p, inv_n, inv_wf)
@@ -3413,6 +3540,14 @@ hipError_t launch_fft_fitness(hipStream_t st, const float *audio, const float *w
                               float inv_n, float inv_wf, uint32_t num_cus, OccCache *oc)
 {
     int *occ_w = oc->fused_win, *occ_n = oc->fused_raw;
+    if (big_from(log2n)) {
+        if (log2n == 14) {
+            if (window) return launch_fft_big<14, 1, true>(st, p, num_cus, audio, nullptr, target, fitness, twiddle, window, inv_n, inv_wf, pitch);
+            return launch_fft_big<14, 1, false>(st, p, num_cus, audio, nullptr, target, fitness, twiddle, nullptr, inv_n, inv_wf, pitch);
+        }
+        if (window) return launch_fft_big<15, 1, true>(st, p, num_cus, audio, nullptr, target, fitness, twiddle, window, inv_n, inv_wf, pitch);
+        return launch_fft_big<15, 1, false>(st, p, num_cus, audio, nullptr, target, fitness, twiddle, nullptr, inv_n, inv_wf, pitch);
+    }
     if (x_from(log2n)) {
         if (window) {
             int *occ_x = oc->x_fused_win;

@@ -47,8 +47,8 @@ def _cfg(hip, **over):
     (dict(struct_size=12), "struct_size"),
     (dict(synth_kind=9), "synth_kind"),
     (dict(num_dimensions=6), "numDimensions"),
-    (dict(audio_length_log2=8), "audioLengthLog2"),
-    (dict(audio_length_log2=14), "audioLengthLog2"),
+    (dict(audio_length_log2=7), "audioLengthLog2"),
+    (dict(audio_length_log2=16), "audioLengthLog2"),
     (dict(num_parents=0), "population"),
     (dict(workgroup_size=0), "workgroupSize"),
     (dict(workgroup_size=24), "workgroupSize"),

@@ -100,7 +100,9 @@ def test_mutate_values_bitexact_steps_close(pkg, O, kind):
     es.close()
 
 
-@pytest.mark.parametrize("kind,log2n", [(0, 10), (1, 11), (2, 10), (3, 12), (0, 9), (0, 13)])
+# N = 256 (k_fft_x with two complex points per lane) and N = 16384 (a workgroup per row for the transform): round 4, the
+# reference takes any audioLengthLog2 (main.cpp:90) and renders 2^14 samples of its best match (main.cpp:273)
+@pytest.mark.parametrize("kind,log2n", [(0, 10), (1, 11), (2, 10), (3, 12), (0, 9), (0, 13), (0, 8), (1, 8), (3, 8), (2, 8), (0, 14), (3, 14), (1, 15)])
 def test_synthesise_bitexact(pkg, O, kind, log2n):
     es, ref = make_pair(pkg, O, 64, 192, kind, log2n)
     es.init_population(0)
@@ -298,7 +300,7 @@ def test_window_bitexact(pkg, O):
     es.close()
 
 
-@pytest.mark.parametrize("log2n", [9, 10, 11, 12, 13])
+@pytest.mark.parametrize("log2n", [8, 9, 10, 11, 12, 13, 14, 15])
 def test_fft_against_fp64(pkg, O, log2n):
     es, _ = make_pair(pkg, O, 16, 48, 0, log2n)
     rng = np.random.default_rng(log2n)
@@ -323,7 +325,7 @@ def test_fft_against_fp64(pkg, O, log2n):
     es.close()
 
 
-@pytest.mark.parametrize("kind,log2n", [(0, 10), (1, 11), (3, 12), (2, 10)])
+@pytest.mark.parametrize("kind,log2n", [(0, 10), (1, 11), (3, 12), (2, 10), (0, 8), (3, 8), (0, 14), (1, 15)])
 def test_fitness_staged_and_fused_against_oracle(pkg, O, kind, log2n):
     es, ref = make_pair(pkg, O, 64, 192, kind, log2n)
     tgt, tv = target_audio(O, kind, es.N)
@@ -524,7 +526,8 @@ def test_lazy_tail_keeps_immigrants_and_full_sort_mode_matches(pkg, O):
 # (the last three: the cut kernels whose helper wavefronts make the genes - one group of 64 per CU, two groups, 3-op)
 @pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (3, 12, 32, 96), (2, 10, 32, 96),
                                                           (0, 9, 16416, 49152), (0, 10, 4096, 12288), (0, 10, 8192, 24576 - 32),
-                                                          (1, 10, 4096 + 32, 12288)])
+                                                          (1, 10, 4096 + 32, 12288), (0, 8, 64, 192), (0, 8, 4096, 12288), (3, 8, 4352, 13056),
+                                                          (0, 14, 32, 96), (3, 14, 300, 724), (1, 15, 16, 48)])
 def test_fused_generation_equals_staged(pkg, O, kind, log2n, parents, offspring):
     a, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
     b, _ = make_pair(pkg, O, parents, offspring, kind, log2n)
