@@ -2829,8 +2829,11 @@ template <int LOG2N> constexpr int x_table_floats() { return 3 * 2 * kWave * (x_
 
 // `image` (fused kernel with window only; may be null): the four tables as they lie in LDS, made once per target by
 // k_x_tables - the workgroups then copy them in by LDS-DMA, one round trip, instead of four dependent-index loads per entry
+#ifndef SOTS_X_MIN_WAVES // (experiment: minimum wavefronts per SIMD the register allocation must allow, e.g. 5 with two workgroups of ten)
+#define SOTS_X_MIN_WAVES 1
+#endif
 template <int LOG2N, int MODE, bool WIN, int WG = x_waves<LOG2N, MODE>()>
-__global__ __launch_bounds__((WG * kWave)) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
+__global__ __launch_bounds__((WG * kWave), (LOG2N == 12 && MODE == 1 ? SOTS_X_MIN_WAVES : 1)) void k_fft_x(const float *__restrict__ audio, float *__restrict__ spectrum,
                                                                    const float *__restrict__ target, float *__restrict__ fitness,
                                                                    const float2 *__restrict__ tw, const float *__restrict__ window,
                                                                    uint32_t p_len, float inv_n, float inv_wf, uint32_t pitch,
