@@ -2,7 +2,7 @@ import importlib, sys, os, numpy as np
 sys.path.insert(0, "/root/repo")
 import bench
 pkg = importlib.import_module(bench.PKG)
-from oracle import oracle as O
+from oracle import oracle as O  # (diagnostic tool: the oracle is the checker here, as in tests/)
 for kind, name, log2n in ((0, "2op", 10), (3, "4op_series", 10), (1, "3op_series", 10)):
     pmax = bench.VOICES[name][0]
     es = pkg.HipES(4096, 12288, kind, log2n, None, pmax, seed=1)
