@@ -1,5 +1,7 @@
+"""Diagnostic (run by hand on a GPU box, not collected by pytest): first mismatching samples of a few rows of each series voice
+against the oracle.  Lives under tests/ because it uses the oracle (test infrastructure)."""
 import importlib, sys, os, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 pkg = importlib.import_module(bench.PKG)
 from oracle import oracle as O  # (diagnostic tool: the oracle is the checker here, as in tests/)
