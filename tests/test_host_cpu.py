@@ -105,3 +105,28 @@ def test_benchmarker_rows_equal_the_reference_class(tmp_path):
     # the plain build's difference columns never exceed the double build's (every difference was truncated towards zero)
     for a, b in zip(absdouble[1:], plain[1:]):
         assert float(b.split(",")[5]) <= float(a.split(",")[5])
+
+
+def test_wav_writer_and_reader_equal_the_reference_audiofile(tmp_path):
+    """SURVEY 8(f)2 pinned by the reference itself: tests/golden/audiofile_24bit_v1.wav is what /root/reference/AudioFile.cpp -
+    compiled as it stands by tests/golden/make_wav_golden.sh - writes for tests/golden/wav_samples.inc through the calls of the
+    reference's outputAudioFile (main.cpp:337-366).  host/Wav_IO.hpp must write the same bytes (header and truncated 24-bit
+    samples, AudioFile.cpp:595) and read the golden file back to what AudioFile::load returns (integer / 8388608, :349-358).
+    The one deliberate difference is outside the fixture: a sample of +1.0 or beyond wraps around in the reference (no clamp); here
+    it is clamped to 0x7FFFFF / 0x800000."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    exe = tmp_path / "wav_driver"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", HOST, "-I", gold, "-o", str(exe), os.path.join(gold, "wav_driver.cpp")])
+    out = tmp_path / "mine.wav"
+    res = subprocess.run([str(exe), str(out), os.path.join(gold, "audiofile_24bit_v1.wav")], check=True, capture_output=True, text=True, timeout=60)
+    assert "read back 1536 samples, 0 differ" in res.stdout
+    mine, ref = out.read_bytes(), open(os.path.join(gold, "audiofile_24bit_v1.wav"), "rb").read()
+    assert len(ref) == 44 + 3 * 1536 and mine == ref
+    # the clamp (the reference would write 0x800000 = -1.0 for +1.0): a two-sample file through a tiny driver
+    src = tmp_path / "clamp.cpp"
+    src.write_text('#include "Wav_IO.hpp"\nint main(int, char **a) { const float x[4] = {1.0f, 7.0f, -3.0f, -1.0f}; outputAudioFile(a[1], x, 4); return 0; }\n')
+    exe2 = tmp_path / "clamp"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", HOST, "-o", str(exe2), str(src)])
+    subprocess.run([str(exe2), str(tmp_path / "c.wav")], check=True, timeout=60)
+    data = (tmp_path / "c.wav").read_bytes()[44:]
+    assert data == bytes([0xFF, 0xFF, 0x7F] * 2 + [0x00, 0x00, 0x80] * 2)
