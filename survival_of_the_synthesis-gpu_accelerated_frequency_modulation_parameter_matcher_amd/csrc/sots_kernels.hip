@@ -849,12 +849,6 @@ template <int OPS> struct OlShape {
     static constexpr int IPW = 4 * R;        // individuals per wavefront: 32 or 16
     static constexpr int NI = IPW / 8;       // store instructions per flush (8 rows x 128 bytes each)
 };
-#ifdef SOTS_OL_PRIO
-#ifndef SOTS_OL_TURN
-#define SOTS_OL_TURN 32
-#endif
-constexpr uint32_t kOlTurn = SOTS_OL_TURN; // trips a wavefront keeps priority 1 before the next one sharing its SIMD gets it (a power of two)
-#endif
 constexpr int kOlTileRows = 256; // individuals per workgroup at most: 256 x 128 bytes of tiles = the 32 KiB beside the table
 template <int OPS> constexpr int ol_max_waves() { return kOlTileRows / OlShape<OPS>::IPW; } // 8 or 16
 
@@ -880,9 +874,7 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
     const int s = (int)grp - (G - OPS);                            // ... i.e. its operator; -1: the 3-operator voice's constant source
     const uint32_t li = (lane >> 4) * R + (lr - grp * R);          // ... of which individual of the wavefront
     const uint32_t rows_per_block = waves * IPW;
-#ifdef SOTS_OL_PRIO
-    const uint32_t turn = wave / 4u, sharers = (waves + 3u) / 4u; // the wavefronts of a workgroup go to the SIMDs in turn: w, w + 4, ... share one
-#endif
+    const uint32_t sharers = (waves + 3u) / 4u; // the wavefronts of a workgroup go to the SIMDs in turn: w, w + 4, ... share one
     float4 *__restrict__ stage = stage_all + wave * (IPW * CH);
     // write side: the last operator's samples are spread over the G lanes of their individual first (row shifts), so that
     // EVERY lane parks 32 / G bytes with one instruction; row = individual, chunk q in slot q ^ (row & 7)
@@ -894,6 +886,9 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
 #pragma unroll
     for (int g = 0; g < NI; ++g) row_off[g] = (lane_off + (uint32_t)g * 8u * pitch) * 4u; // bytes; < 2^32: 32 rows of at most 8224 floats
 
+    // progress counters of the wavefronts (below): 64 bytes behind the tiles, where the workgroup leaves them (fewer than 256 rows)
+    int *__restrict__ progress = reinterpret_cast<int *>(stage_all + rows_per_block * CH);
+    const bool feedback = sharers > 1u && rows_per_block * CH + 4u <= (uint32_t)(kOlTileRows * CH);
     const uint32_t first_base = blockIdx.x * rows_per_block;
     for (uint32_t base = first_base; base < p_len; base += gridDim.x * rows_per_block) {
         const uint32_t row0 = base + wave * IPW; // first row of this wavefront
@@ -1056,6 +1051,7 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
                 }
             }
         };
+        if (feedback && lane == 0) progress[wave] = 0; // (a stale count of the tile before only costs a priority)
         constexpr uint32_t K0 = 2 * OPS; // first trip (even) in which every operator works and samples leave
         SOTS_STAMP_SCOPE(blockIdx.x * (blockDim.x / kWave) + wave); // (diagnostic builds: this wavefront's cycles over all trips)
         for (uint32_t k = 0; k < K0; k += 2) {
@@ -1063,14 +1059,22 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
             trip(ic<1>{}, ic<1>{}, k + 1);
         }
         for (uint32_t k = K0; k < nb; k += 2) {
-#ifdef SOTS_OL_PRIO // (experiment, off: it evens the wavefronts out at the SLOW end - 75 / 92 against 65 / 94 cycles per sample)
-            // The SIMD issues for its OLDEST wavefront first: of two that share it the older runs as if alone (54 cycles per
-            // sample in isolation) and the younger takes what is left (78) - and the kernel ends with the younger.  The
-            // wavefronts that share a SIMD (w, w + 4, ... of the workgroup) take turns at priority 1, kOlTurn trips each (a
-            // turn per trip costs more than it brings: the taken branch around s_setprio's immediate is ~100 cycles).
-            if ((k & (kOlTurn - 1u)) == 0u) {
-                const uint32_t mine = __builtin_amdgcn_readfirstlane(((k / kOlTurn) % sharers) == turn ? 1u : 0u);
-                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n\ts_branch 2f\n1:\ts_setprio 0\n2:" ::"s"(mine));
+#ifndef SOTS_OL_NO_FEEDBACK
+            // The SIMD issues for its OLDEST wavefront first: of two that share it the older runs as if alone (54 cycles per sample in
+            // isolation) and the younger takes what is left (78) - and the kernel ends with the younger.  Every 16 trips a wavefront
+            // publishes its trip count in LDS and takes priority = the number of wavefronts sharing its SIMD (w, w + 4, ... of the
+            // workgroup) that are AHEAD of it, so the laggard issues first: 70 / 71 in isolation (tools/ubench/ol_loop.hip).
+            // (Priority TURNS - a trip each, or 32 - even the two out at the slow end; s_setprio takes an immediate, hence the branches.)
+            if (feedback && (k & 15u) == 0u) {
+                if (lane == 0) __hip_atomic_store(&progress[wave], (int)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                uint32_t ahead = 0;
+                for (uint32_t q = 1; q < sharers; ++q) {
+                    const uint32_t other = (wave + 4u * q) % (4u * sharers);
+                    ahead += other < waves && __hip_atomic_load(&progress[other], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (int)k ? 1u : 0u;
+                }
+                ahead = __builtin_amdgcn_readfirstlane(ahead);
+                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 10f\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 11f\n\ts_cmp_eq_u32 %0, 2\n\ts_cbranch_scc1 12f\n\t"
+                             "s_setprio 3\n\ts_branch 19f\n10:\ts_setprio 0\n\ts_branch 19f\n11:\ts_setprio 1\n\ts_branch 19f\n12:\ts_setprio 2\n19:" ::"s"(ahead));
             }
 #endif
             trip(ic<0>{}, ic<0>{}, k);

@@ -114,8 +114,30 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, i
             asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n\ts_branch 2f\n1:\ts_setprio 0\n2:" ::"s"(mine));
         }
     };
+    // MODE & 4096: progress feedback - every 16 trips a wavefront publishes its trip count in LDS and takes priority = the number
+    // of wavefronts sharing its SIMD (w, w + 4, w + 8, w + 12 of the workgroup) that are AHEAD of it: the laggard issues first
+    __shared__ int progress[16];
+    if (threadIdx.x < 16) progress[threadIdx.x] = 0;
+    __syncthreads();
+    const int my_wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    auto feedback = [&](int k) {
+        if constexpr (MODE & 4096) {
+            if ((k & 15) == 0) {
+                if (lane == 0) progress[my_wave] = k;
+                int ahead = 0;
+                for (int q = 1; q < sharers; ++q) {
+                    const int other = (my_wave + 4 * q) % (4 * sharers);
+                    ahead += *(volatile int *)&progress[other] > k ? 1 : 0;
+                }
+                ahead = __builtin_amdgcn_readfirstlane(ahead);
+                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 10f\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 11f\n\ts_cmp_eq_u32 %0, 2\n\ts_cbranch_scc1 12f\n\t"
+                             "s_setprio 3\n\ts_branch 19f\n10:\ts_setprio 0\n\ts_branch 19f\n11:\ts_setprio 1\n\ts_branch 19f\n12:\ts_setprio 2\n19:" ::"s"(ahead));
+            }
+        }
+    };
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int k = 0; k < trips; k += 2) {
+        feedback(k);
         prio(k);
         if constexpr (MODE & 2048) __builtin_amdgcn_s_setprio(1); // the SAME pattern in every wavefront: even trips at priority 1, odd at 0
         trip(std::integral_constant<int, 0>{});
@@ -160,6 +182,7 @@ int main()
     run<64>("plain instead of packed hand-over arithmetic", out, cyc);
     run<128>("no hand-over arithmetic", out, cyc);
     run<1024>("full trip, row shift folded into the phase add", out, cyc);
+    run<4096>("full trip, priority by progress feedback", out, cyc);
     run<1024 + 2048>("folded, static priority 1 in even trips, 0 in odd", out, cyc);
     run<512>("full trip, priority by turns", out, cyc);
     run<64 + 512>("plain hand-over arithmetic, priority by turns", out, cyc);
