@@ -3296,16 +3296,16 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         }
         return hipGetLastError();
     }
-    // The 4-operator voice at 65 ... 128 individuals per CU (BASELINE configs[3]'s shard): the operators in the lanes (k_synth_ol) -
-    // every wavefront carries 16 individuals, eight wavefronts per CU without hand-overs or barriers: 180 against 189 us, 337 against
-    // 357 us per generation in a same-box A/B.  Everywhere else the kernels above measure faster (2-op P = 65 536: 51 against 55 us;
-    // 3-op N = 2048: 137 against 170; 4-op at 256 per CU: 327 against 343; profiles/r04_experiments.md), so `SOTS_OL_ALL` is an
-    // experiment switch.
+    // The 3- and 4-operator voices at 65 ... 128 individuals per CU (BASELINE configs[3]'s shard): the operators in the lanes
+    // (k_synth_ol) - every wavefront carries 16 individuals, eight wavefronts per CU without hand-overs or barriers: 4-op N = 4096
+    // 174 against 189 us, 330 against 357 us per generation in same-box A/Bs; 3-op N = 2048 P = 32 768 91 against 95 us.  Everywhere
+    // else the kernels above measure faster (2-op P = 65 536: 51 against 55 us; 3-op P = 65 536: 137 against 170, P = 16 384: 64
+    // against 76; 4-op at 256 per CU: 327 against 343; profiles/r04_experiments.md), so `SOTS_OL_ALL` is an experiment switch.
 #ifndef SOTS_SYNTH_NO_OL
 #ifdef SOTS_OL_ALL
     const bool use_ol = allow_cut && kind != SOTS_SYNTH_TRIPLE_PAR && share >= (uint32_t)SOTS_OL_MIN_SHARE;
 #else
-    const bool use_ol = allow_cut && kind == SOTS_SYNTH_4OP_SERIES && share > 64u && share <= 128u;
+    const bool use_ol = allow_cut && (kind == SOTS_SYNTH_4OP_SERIES || kind == SOTS_SYNTH_3OP_SERIES) && share > 64u && share <= 128u;
 #endif
     if (use_ol) {
         auto launch_ol = [&](auto kind_tag) {
