@@ -96,6 +96,20 @@ def test_sots_match_cli(tmp_path, O):
     assert rate > 0
     cfg["type"]["HIP"].update({"numDevices": 1})
     cfg["type"]["HIP"].pop("devices")
+    # the shortest and a long analysis block (audioLengthLog2 8 and 14, round 4): the driver, the C++ class and the host tables take them
+    for log2n in (8, 14):
+        cfg["type"]["HIP"].update({"numDevices": 1})
+        cfg["type"]["HIP"].pop("devices", None)
+        cfg["audio"]["audioLengthLog2"] = log2n
+        cfg["evolutionary"]["numGenerations"] = 12
+        cfg["evolutionary"]["numParents"], cfg["evolutionary"]["numOffspring"] = 256, 768
+        p.write_text(json.dumps(cfg))
+        out = subprocess.run([exe, "-j", str(p)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+        assert out.returncode == 0, out.stderr
+        assert np.isfinite(float(out.stdout.split("Fitness = ")[1].split()[0]))
+        _, _, _, _, gen = read_wav24(tmp_path / "inputGenerated.wav")
+        assert len(gen) == 1 << log2n
+    cfg["audio"]["audioLengthLog2"] = 10
     # wrong implementation is refused
     cfg["type"]["implementation"] = "OpenCL"
     p.write_text(json.dumps(cfg))
