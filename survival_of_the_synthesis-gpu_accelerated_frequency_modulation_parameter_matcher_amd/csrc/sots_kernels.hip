@@ -535,6 +535,9 @@ __global__ __launch_bounds__((HELP ? (SPLIT ? 8 : 16) : SPLIT3 ? 8 : SPLIT2 ? 6 
             gain[0] = p[2 * (OPS - 1)] * p[2 * (OPS - 1) + 1];
         }
         // a free-running phase stays inside [0, W) when 0 <= inc0 < W: its index needs no clamp
+        // (round 4: the modulated phases likewise, where every increment they can receive is bounded by c (|mul| + |off|) < W - the
+        // unsigned conversion and one two-operand minimum instead of the signed one and v_med3_i32: no difference here, 51.0-51.3
+        // against 51.3-51.4 us; k_synth_ol, where the index goes clamp-FREE on that condition, gains 8 %)
         bool in_range = true;
 #pragma unroll
         for (int j = 0; j < J; ++j) in_range = in_range && inc0[j] >= 0.0f && inc0[j] < kWf;
@@ -849,8 +852,8 @@ template <int OPS> struct OlShape {
     static constexpr int IPW = 4 * R;        // individuals per wavefront: 32 or 16
     static constexpr int NI = IPW / 8;       // store instructions per flush (8 rows x 128 bytes each)
 };
-constexpr int kOlTileRows = 256; // individuals per workgroup at most: 256 x 128 bytes of tiles = the 32 KiB beside the table
-template <int OPS> constexpr int ol_max_waves() { return kOlTileRows / OlShape<OPS>::IPW; } // 8 or 16
+constexpr int kOlTileRows = 240; // individuals per workgroup at most: 240 x 128 bytes of tiles + the table's spare entry in the 32 KiB beside the table
+template <int OPS> constexpr int ol_max_waves() { return kOlTileRows / OlShape<OPS>::IPW; } // 7 or 15
 
 template <int KIND>
 __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void k_synth_ol(const float *__restrict__ values,
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
     constexpr int G = OlShape<OPS>::G, R = OlShape<OPS>::R, IPW = OlShape<OPS>::IPW, NI = OlShape<OPS>::NI;
     constexpr int U = 8, CH = kStageChunks;
     constexpr int LAST = 2 * OPS - 1; // the block whose samples leave in trip k is k - LAST
-    __shared__ float tab[kWavetableSize];
+    __shared__ float tab[kWavetableSize + 64]; // entry W repeats entry W - 1: the clamp-free index below may reach it
     __shared__ float4 stage_all[kOlTileRows * CH];
     request_wavetable(tab, wavetable);
     bool table_pending = true;
@@ -937,9 +940,22 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
         const float wlo = s <= 0 ? 0.0f : kWf; // operator 0 has the first wrap only
         if (table_pending) {
             wavetable_ready();
+            if (threadIdx.x == 0) tab[kWavetableSize] = tab[kWavetableSize - 1];
+            __syncthreads();
             table_pending = false;
         }
+        // The index needs no clamp while every phase stays inside [0, W]: operator 0's increment in [0, W) (first wrap only), and
+        // every handed-over increment c (t pm + po) smaller than W in magnitude - |t| <= 1, so c (|pm| + |po|) < W suffices, whatever
+        // the table says (the lanes run on past their last block and before their first: only bounds that hold for every table
+        // value count).  A phase that the second wrap's addition rounds up to exactly W reads entry W = entry W - 1, which is what
+        // the reference's clamp makes of it (tab_at).  The reference's own parameter box qualifies (0.743 (3520 x 8 + 3520) < 32768);
+        // any lane out of bounds, or NaN, sends the wavefront down the clamped path.
+        const bool hands_over = s >= 0 && s < OPS - 1;
+        const bool lane_bounded = (!hands_over || c * (__builtin_fabsf(pm) + __builtin_fabsf(po)) < 0.999f * kWf) && inc0c >= 0.0f && inc0c < kWf;
+        const bool unclamped = __all(lane_bounded);
 
+        auto run = [&](auto unclamped_tag) {
+        constexpr bool UNCLAMPED = decltype(unclamped_tag)::value;
         float pos = 0.0f;
         float inc[U];  // this lane's increments for the block it works on next (operator 0: the constant, never overwritten)
         float T[2][U]; // table values of the block of this trip's parity / of the trip before
@@ -971,7 +987,9 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
 #elif SOTS_OL_ABL & 16 // conflict-free table reads (no index arithmetic either)
                 T[Q][u] = tab[lane + 64 * u];
 #else
-                {
+                if constexpr (UNCLAMPED) {
+                    T[Q][u] = tab[(uint32_t)pos]; // pos in [0, W]
+                } else {
                     // table[clamp((int)pos, 0, W-1)] (tab_at): v_cvt_u32_f32 saturates - negative and NaN give 0, as the
                     // oracle's tab_at does - then one unsigned minimum; both cheaper to issue than the signed med3
                     uint32_t ti;
@@ -1085,6 +1103,13 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
             trip(ic<1>{}, ic<2>{}, k + 1);
         }
         store_pending();
+        };
+#ifdef SOTS_OL_CLAMPED // (experiment: the clamped index for every wavefront)
+        run(std::false_type{});
+#else
+        if (unclamped) run(std::true_type{});
+        else run(std::false_type{});
+#endif
     }
     if (table_pending) wavetable_ready(); // a workgroup without a tile must not end with copies in flight
 }
