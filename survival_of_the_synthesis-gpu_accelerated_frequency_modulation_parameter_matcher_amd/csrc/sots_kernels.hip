@@ -864,7 +864,12 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
     constexpr int OPS = VoiceShape<KIND>::OPS, D = VoiceShape<KIND>::D;
     static_assert(VoiceShape<KIND>::J == 1, "series voices");
     constexpr int G = OlShape<OPS>::G, R = OlShape<OPS>::R, IPW = OlShape<OPS>::IPW, NI = OlShape<OPS>::NI;
-    constexpr int U = 8, CH = kStageChunks;
+#ifndef SOTS_OL_U
+#define SOTS_OL_U 16
+#endif
+    // samples per trip: 16 where a lane is one of four per individual (the per-trip work - tile addresses, the flush test, loop and
+    // priority bookkeeping - over twice the samples: 157 -> 146-150 us at configs[3]'s shard; 32 would not fit 128 registers), 8 for the 2-operator layout
+    constexpr int U = G == 4 ? SOTS_OL_U : 8, CH = kStageChunks;
     constexpr int LAST = 2 * OPS - 1; // the block whose samples leave in trip k is k - LAST
     __shared__ float tab[kWavetableSize + 64]; // entry W repeats entry W - 1: the clamp-free index below may reach it
     __shared__ float4 stage_all[kOlTileRows * CH];
@@ -1042,7 +1047,13 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
                 auto shl = [&](float keep, float src, auto n_tag) {
                     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x100 + decltype(n_tag)::value, 0xf, 0xf, false));
                 };
-                if constexpr (G == 4) {
+                if constexpr (G == 4 && U == 16) { // 16-sample trips: a whole chunk of 16 bytes per lane
+                    float4 w = make_float4(m[6].x, m[6].y, m[7].x, m[7].y);
+                    w.x = shl(w.x, m[4].x, ic<R>{}), w.y = shl(w.y, m[4].y, ic<R>{}), w.z = shl(w.z, m[5].x, ic<R>{}), w.w = shl(w.w, m[5].y, ic<R>{});
+                    w.x = shl(w.x, m[2].x, ic<2 * R>{}), w.y = shl(w.y, m[2].y, ic<2 * R>{}), w.z = shl(w.z, m[3].x, ic<2 * R>{}), w.w = shl(w.w, m[3].y, ic<2 * R>{});
+                    w.x = shl(w.x, m[0].x, ic<3 * R>{}), w.y = shl(w.y, m[0].y, ic<3 * R>{}), w.z = shl(w.z, m[1].x, ic<3 * R>{}), w.w = shl(w.w, m[1].y, ic<3 * R>{});
+                    stage[li * CH + ((c0 + grp) ^ l7)] = w;
+                } else if constexpr (G == 4) {
                     v2f_t w = m[3];
                     w.x = shl(w.x, m[2].x, ic<R>{}), w.y = shl(w.y, m[2].y, ic<R>{});
                     w.x = shl(w.x, m[1].x, ic<2 * R>{}), w.y = shl(w.y, m[1].y, ic<2 * R>{});
