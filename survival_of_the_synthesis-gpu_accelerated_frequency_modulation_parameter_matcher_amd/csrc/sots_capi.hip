@@ -763,10 +763,9 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
                                                                    // small populations of the 2- and 3-operator voices: the cut kernel's helper wavefronts (launch_synth);
                                                                    // with 8 genes it is a draw (204 = 204 us at P = 1024, 373 against 368 at 32768)
                                                                    (ctx->pd.d <= 6 && ctx->cfg.synth_kind != SOTS_SYNTH_TRIPLE_PAR && ctx->allow_cut && ctx->P <= 128u * (ctx->num_cus ? ctx->num_cus : 256u)) ||
-                                                                   // 4-operator voice with a wavefront per operator (65 ... 128 individuals per CU): all eight wavefronts make
-                                                                   // two genes per thread first (361 against 363 us per generation at configs[3]'s shard)
-                                                                   (ctx->cfg.synth_kind == SOTS_SYNTH_4OP_SERIES && ctx->allow_cut && ctx->P > 64u * (ctx->num_cus ? ctx->num_cus : 256u) &&
-                                                                    ctx->P <= 128u * (ctx->num_cus ? ctx->num_cus : 256u));
+                                                                   // 3- and 4-operator voices from 65 individuals per CU: k_synth_ol (round 4) makes its workgroup's
+                                                                   // individuals first, a thread per gene, whatever the number of genes
+                                                                   (ctx->allow_cut && synth_operators_in_lanes(ctx->cfg.synth_kind, ctx->P, ctx->num_cus));
         if (!fuse_variation) {
             StageScope t(ctx, SOTS_STAGE_FUSED_VARIATION, true);
             SOTS_HIP(ctx, launch_recombine_mutate(ctx->stream, ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst),

@@ -90,6 +90,8 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 // Small populations of the series voices: the synthesis kernel with the time axis in the lanes applies (it makes its own
 // individuals from one thread per gene when given a Variation, whatever the number of genes)
 bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus);
+// ... and where the series voices run with the operators in the lanes (k_synth_ol: the workgroup makes its individuals too, a thread per gene)
+bool synth_operators_in_lanes(uint32_t kind, uint32_t p, uint32_t num_cus);
 // Audio rows are `pitch` floats apart (pitch >= N, a multiple of 4): a power-of-two row stride
 // would put every lane of a row-per-lane store on the same memory channel.
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,

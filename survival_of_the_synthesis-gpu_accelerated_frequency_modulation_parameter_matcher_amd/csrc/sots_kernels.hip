@@ -869,10 +869,13 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
 #endif
     // samples per trip: 16 where a lane is one of four per individual (the per-trip work - tile addresses, the flush test, loop and
     // priority bookkeeping - over twice the samples: 157 -> 146-150 us at configs[3]'s shard; 32 would not fit 128 registers), 8 for the 2-operator layout
-    constexpr int U = G == 4 ? SOTS_OL_U : 8, CH = kStageChunks;
+#ifndef SOTS_OL_U2
+#define SOTS_OL_U2 8
+#endif
+    constexpr int U = G == 4 ? SOTS_OL_U : SOTS_OL_U2, CH = kStageChunks;
     constexpr int LAST = 2 * OPS - 1; // the block whose samples leave in trip k is k - LAST
     __shared__ float tab[kWavetableSize + 64]; // entry W repeats entry W - 1: the clamp-free index below may reach it
-    __shared__ float4 stage_all[kOlTileRows * CH];
+    __shared__ float4 stage_all[kOlTileRows * CH + 4]; // the tiles + 64 bytes of progress counters
     request_wavetable(tab, wavetable);
     bool table_pending = true;
     const float c = (float)kWavetableSize / (float)SOTS_SAMPLE_RATE; // w2srRatio, Evolutionary_Strategy.hpp:203
@@ -894,9 +897,9 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
 #pragma unroll
     for (int g = 0; g < NI; ++g) row_off[g] = (lane_off + (uint32_t)g * 8u * pitch) * 4u; // bytes; < 2^32: 32 rows of at most 8224 floats
 
-    // progress counters of the wavefronts (below): 64 bytes behind the tiles, where the workgroup leaves them (fewer than 256 rows)
+    // progress counters of the wavefronts (below): 64 bytes behind the workgroup's tiles
     int *__restrict__ progress = reinterpret_cast<int *>(stage_all + rows_per_block * CH);
-    const bool feedback = sharers > 1u && rows_per_block * CH + 4u <= (uint32_t)(kOlTileRows * CH);
+    const bool feedback = sharers > 1u;
     const uint32_t first_base = blockIdx.x * rows_per_block;
     for (uint32_t base = first_base; base < p_len; base += gridDim.x * rows_per_block) {
         const uint32_t row0 = base + wave * IPW; // first row of this wavefront
@@ -1060,6 +1063,12 @@ __global__ __launch_bounds__(ol_max_waves<VoiceShape<KIND>::OPS>() * kWave) void
                     w.x = shl(w.x, m[0].x, ic<3 * R>{}), w.y = shl(w.y, m[0].y, ic<3 * R>{});
                     float2 *__restrict__ wr2 = reinterpret_cast<float2 *>(stage + li * CH);
                     wr2[((c0 + (grp >> 1)) ^ l7) * 2u + (grp & 1u)] = make_float2(w.x, w.y);
+                } else if constexpr (U == 16) { // two lanes per individual, 16-sample trips: two chunks per lane
+                    float4 w0 = make_float4(m[4].x, m[4].y, m[5].x, m[5].y), w1 = make_float4(m[6].x, m[6].y, m[7].x, m[7].y);
+                    w0.x = shl(w0.x, m[0].x, ic<R>{}), w0.y = shl(w0.y, m[0].y, ic<R>{}), w0.z = shl(w0.z, m[1].x, ic<R>{}), w0.w = shl(w0.w, m[1].y, ic<R>{});
+                    w1.x = shl(w1.x, m[2].x, ic<R>{}), w1.y = shl(w1.y, m[2].y, ic<R>{}), w1.z = shl(w1.z, m[3].x, ic<R>{}), w1.w = shl(w1.w, m[3].y, ic<R>{});
+                    stage[li * CH + ((c0 + 2u * grp) ^ l7)] = w0;
+                    stage[li * CH + ((c0 + 2u * grp + 1u) ^ l7)] = w1;
                 } else {
                     float4 w = make_float4(m[2].x, m[2].y, m[3].x, m[3].y);
                     w.x = shl(w.x, m[0].x, ic<R>{}), w.y = shl(w.y, m[0].y, ic<R>{}), w.z = shl(w.z, m[1].x, ic<R>{}), w.w = shl(w.w, m[1].y, ic<R>{});
@@ -3294,6 +3303,21 @@ hipError_t launch_recombine_mutate(hipStream_t st, const float *vin, const float
 #ifndef SOTS_OL_MIN_SHARE
 #define SOTS_OL_MIN_SHARE 48
 #endif
+// Where k_synth_ol runs (same-box A/Bs, profiles/r04_experiments.md): the 4-operator voice from 65 individuals per CU (65 ... 240
+// in one tile: 128 per CU 146-157 against 189 us, 192 per CU 199 against 297; beyond that in equal tiles: 256 per CU 302-307 against 313-317 + the
+// variation launch, 313 per CU 389 against 612), the 3-operator voice at 65 ... 240 (128 per CU 91 against 95, 192 per CU 106 against
+// 128; at 256 and 512 per CU k_synth wins: 126 against 152, 254 against 310)
+bool synth_operators_in_lanes(uint32_t kind, uint32_t p, uint32_t num_cus)
+{
+#ifdef SOTS_SYNTH_NO_OL
+    return false;
+#else
+    const uint32_t cus = num_cus ? num_cus : 256u, share = (p + cus - 1) / cus;
+    if (kind == SOTS_SYNTH_4OP_SERIES) return share > 64u;
+    if (kind == SOTS_SYNTH_3OP_SERIES) return share > 64u && share <= (uint32_t)kOlTileRows;
+    return false;
+#endif
+}
 bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
 {
 #ifdef SOTS_SYNTH_NO_TP
@@ -3332,22 +3356,23 @@ hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, cons
         }
         return hipGetLastError();
     }
-    // The 3- and 4-operator voices at 65 ... 128 individuals per CU (BASELINE configs[3]'s shard): the operators in the lanes
-    // (k_synth_ol) - every wavefront carries 16 individuals, eight wavefronts per CU without hand-overs or barriers: 4-op N = 4096
-    // 174 against 189 us, 330 against 357 us per generation in same-box A/Bs; 3-op N = 2048 P = 32 768 91 against 95 us.  Everywhere
-    // else the kernels above measure faster (2-op P = 65 536: 51 against 55 us; 3-op P = 65 536: 137 against 170, P = 16 384: 64
-    // against 76; 4-op at 256 per CU: 327 against 343; profiles/r04_experiments.md), so `SOTS_OL_ALL` is an experiment switch.
+    // The 3- and 4-operator voices from 65 individuals per CU (BASELINE configs[3]'s shard: 128): the operators in the lanes
+    // (k_synth_ol; where exactly: synth_operators_in_lanes above) - every wavefront carries 16 individuals, up to fifteen wavefronts per
+    // CU without hand-overs or barriers.  The 2-operator voice stays on k_synth (224 per CU: 49.3 against 51.1 us, and 256 per CU - BASELINE
+    // configs[2] - leaves no LDS for the spare table entry and the progress counters); `SOTS_OL_ALL` is an experiment switch.
 #ifndef SOTS_SYNTH_NO_OL
 #ifdef SOTS_OL_ALL
     const bool use_ol = allow_cut && kind != SOTS_SYNTH_TRIPLE_PAR && share >= (uint32_t)SOTS_OL_MIN_SHARE;
 #else
-    const bool use_ol = allow_cut && (kind == SOTS_SYNTH_4OP_SERIES || kind == SOTS_SYNTH_3OP_SERIES) && share > 64u && share <= 128u;
+    const bool use_ol = allow_cut && synth_operators_in_lanes(kind, p, num_cus);
 #endif
     if (use_ol) {
         auto launch_ol = [&](auto kind_tag) {
             constexpr int K = decltype(kind_tag)::value, OPS = VoiceShape<K>::OPS, IPW = OlShape<OPS>::IPW;
             constexpr uint32_t max_rows = ol_max_waves<OPS>() * IPW;
-            uint32_t rows = (share + IPW - 1) / IPW * IPW;
+            // a CU's share in equal tiles of at most max_rows rows (256 per CU: two tiles of 128, not 240 + 16)
+            const uint32_t tiles_per_cu = (share + max_rows - 1) / max_rows;
+            uint32_t rows = ((share + tiles_per_cu - 1) / tiles_per_cu + IPW - 1) / IPW * IPW;
             rows = rows > max_rows ? max_rows : rows;
             uint32_t grid = (p + rows - 1) / rows;
             grid = grid > cus ? cus : grid; // larger populations: a workgroup takes several tiles
