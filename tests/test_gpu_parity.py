@@ -175,12 +175,13 @@ def test_synthesise_two_op_large_population_uses_lane_per_individual_kernel(pkg,
     es.close()
 
 
-# k_synth_ol (round 4): the 3- and 4-operator voices at 65 ... 128 individuals per CU (BASELINE configs[3]'s shard) run with the
-# OPERATORS in the lanes - a row of 16 lanes holds 4 individuals, hand-over by DPP row shifts, no LDS links, no barriers.
-# Sizes: configs[3]'s shard; the same with a partly filled last workgroup; a ragged population (recombination blocks of 1) in wild
-# parameter boxes (negative and beyond-table increments: operator 0 has the first wrap only, the index clamp acts on both sides);
-# the other voices and sizes (kernels of rounds 1-3; with -DSOTS_OL_ALL the same kernel for the 2- and 3-operator voices and for
-# populations of several tiles per workgroup) keep their cases.
+# k_synth_ol (round 4): the 4-operator voice from 65 individuals per CU (BASELINE configs[3]'s shard: 128) and the 3-operator voice at
+# 65 ... 240 run with the OPERATORS in the lanes - a row of 16 lanes holds 4 individuals, hand-over by DPP row shifts, no LDS links,
+# no barriers; tiles of up to 240 rows, larger shares in several equal tiles.
+# Sizes: configs[3]'s shard; the same with a partly filled last workgroup; ragged populations (recombination blocks of 1) in wild
+# parameter boxes (negative and beyond-table increments: operator 0 has the first wrap only, the index clamp acts on both sides - the
+# clamped path; the reference's box takes the clamp-free one); 313 per CU (two tiles of 160) and 274 per CU of the 3-operator voice
+# (k_synth there); the 2-operator voice (k_synth; with -DSOTS_OL_ALL the same kernel with two lanes per individual) keeps its cases.
 @pytest.mark.parametrize("kind,log2n,parents,offspring,wild", [
     (3, 12, 8192, 24576, False), (3, 9, 8192, 24416, False), (3, 9, 5000, 15011, True), (3, 10, 4352, 13056, False),
     (0, 10, 4096, 12288, False), (0, 9, 3333, 9987, True), (0, 10, 16640, 49920 + 32 * 700, False),
