@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: world_size-2 and -3 island runs over gloo, one process per island,
+"""The N > 1 path on CPU: world_size-2, -3 and -8 island runs over gloo, one process per island,
 checked against a single-process simulation of the same islands.  The evaluator is the CPU
 oracle; the exchange code (island.IslandExchange) is the one bench.py uses over RCCL."""
 import os
@@ -46,7 +46,9 @@ def simulate(O, world, gens, elites, overlap, parents=32, offspring=96):
 
 # (80, 176): numParents is not a multiple of the recombination block of 32, so the rows recombination reads are the two
 # whole parent blocks (64 rows) and the immigrants sit at THEIR tail, rows 64 - n .. 63
-@pytest.mark.parametrize("world,overlap,parents,offspring", [(2, 0, 32, 96), (3, 0, 32, 96), (2, 1, 32, 96), (3, 1, 32, 96), (2, 0, 80, 176)])
+# world 8 (round 4): the rank count of BASELINE configs[3] / [4] - 7 x 4 immigrants fit the 32 rows recombination reads
+@pytest.mark.parametrize("world,overlap,parents,offspring", [(2, 0, 32, 96), (3, 0, 32, 96), (2, 1, 32, 96), (3, 1, 32, 96), (2, 0, 80, 176),
+                                                             (8, 0, 32, 96), (8, 1, 32, 96)])
 def test_island_exchange_over_gloo(tmp_path, O, world, overlap, parents, offspring):
     gens, elites = 4, 4
     port = free_port()
