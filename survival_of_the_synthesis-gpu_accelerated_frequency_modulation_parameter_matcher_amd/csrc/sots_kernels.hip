@@ -2293,15 +2293,24 @@ __device__ __forceinline__ void bitonic_merge(uint32_t &b, uint32_t &i, uint32_t
     if constexpr (J > 1) bitonic_merge<K, J / 2>(b, i, lane);
 }
 
+// SPLIT workgroups per tile (blockIdx = tile + part * tiles): a tile is 16 wavefronts on ONE CU, and with the 64 tiles of
+// P = 65536 three quarters of the GPU idle while each of those CUs answers 1440 wavefront-wide LDS reads of the searches.
+// Every workgroup of a tile sorts all 16 runs (the searches need them; the register network is cheap), then only the
+// wavefronts of ITS runs - a quarter, one per SIMD - search and write.
+#ifndef SOTS_SEL_SPLIT
+#define SOTS_SEL_SPLIT 4
+#endif
+template <uint32_t SPLIT>
 __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict__ fitness, uint32_t *__restrict__ kbits,
                                                          uint32_t *__restrict__ kidx, uint32_t *__restrict__ samples,
-                                                         uint32_t p_len)
+                                                         uint32_t p_len, uint32_t tiles)
 {
     constexpr uint32_t kRuns = kSelTile / kWave;
     __shared__ uint32_t runs[kSelTile];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const uint32_t g = blockIdx.x * kSelTile + tid;
+    const uint32_t tile = SPLIT == 1 ? blockIdx.x : blockIdx.x % tiles, part = SPLIT == 1 ? 0u : blockIdx.x / tiles;
+    const uint32_t g = tile * kSelTile + tid;
     SOTS_PHASE_BEGIN();
     uint32_t b = g < p_len ? order_bits(fitness[g]) : kSelPadBits, i = g; // padding keys sort last, by index
 #ifdef SOTS_STAMP
@@ -2317,6 +2326,7 @@ __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict_
     runs[tid] = b;
     __syncthreads();
     SOTS_PHASE(9);
+    if (SPLIT > 1 && wave / (kRuns / SPLIT) != part) return;
     // place in the tile = lane + lower bounds in the other 15 runs, all 15 searches advanced level by level so
     // that the LDS reads of a level are in flight together.  A run of an earlier wavefront holds lower indices,
     // so its equal keys come first (count <=, i.e. < b + 1), a later run's do not (<).
@@ -2335,12 +2345,12 @@ __global__ __launch_bounds__(kSelTile) void k_sel_tiles(const float *__restrict_
 #pragma unroll
     for (uint32_t w = 0; w < kRuns; ++w) rank += pos[w] - w * kWave + (runs[pos[w]] < thr[w] ? 1u : 0u);
     SOTS_PHASE(10);
-    const size_t o = (size_t)blockIdx.x * kSelTile + rank;
+    const size_t o = (size_t)tile * kSelTile + rank;
     kbits[o] = b;
     kidx[o] = i;
     if ((rank & (kSelQuantum - 1)) == kSelQuantum - 1) {
-        samples[blockIdx.x * kSelSamples + rank / kSelQuantum] = b;
-        samples[gridDim.x * kSelSamples + blockIdx.x * kSelSamples + rank / kSelQuantum] = i; // indices behind all the bits
+        samples[tile * kSelSamples + rank / kSelQuantum] = b;
+        samples[tiles * kSelSamples + tile * kSelSamples + rank / kSelQuantum] = i; // indices behind all the bits
     }
     SOTS_PHASE(11);
 }
@@ -3813,7 +3823,10 @@ hipError_t launch_select(hipStream_t st, const float *vin, const float *sin, con
     const uint32_t n_pad = sel_pad(p);
     const uint32_t tiles = n_pad / kSelTile;
     uint32_t *kbits = reinterpret_cast<uint32_t *>(keys), *kidx = kbits + n_pad, *samples = kidx + n_pad;
-    k_sel_tiles<<<tiles, kSelTile, 0, st>>>(fin, kbits, kidx, samples, p);
+    // (split while the parts still find CUs of their own; the 128 tiles of P = 131072 stay whole)
+    if (SOTS_SEL_SPLIT > 1 && tiles * SOTS_SEL_SPLIT <= (num_cus ? num_cus : 256))
+        k_sel_tiles<SOTS_SEL_SPLIT><<<tiles * SOTS_SEL_SPLIT, kSelTile, 0, st>>>(fin, kbits, kidx, samples, p, tiles);
+    else k_sel_tiles<1><<<tiles, kSelTile, 0, st>>>(fin, kbits, kidx, samples, p, tiles);
     // one workgroup per CU (the staging buffer takes the LDS); more only when a share of the staged
     // positions would exceed the per-workgroup key store
     uint32_t grid = num_cus ? num_cus : 256;
