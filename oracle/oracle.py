@@ -61,6 +61,7 @@ def lib():
     L.sots_or_synth_dims.argtypes = [C.c_uint32]
     L.sots_or_synth_dims.restype = C.c_uint32
     L.sots_or_synth.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p, C.c_uint32, f32p]
+    L.sots_or_synth_ocl.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p, C.c_uint32, f32p, C.c_uint32]
     L.sots_or_spectrum.argtypes = [f32p, C.c_uint32, f64p, C.c_float, f32p]
     L.sots_or_rfft.argtypes = [f32p, C.c_uint32, f64p, f64p, f64p]
     L.sots_or_rfft_naive.argtypes = [f32p, C.c_uint32, f64p, f64p, f64p]
@@ -70,6 +71,9 @@ def lib():
     L.sots_or_recombine.argtypes = [f32p, f32p, f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.sots_or_mutate.argtypes = [f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
     L.sots_or_sort_perm.argtypes = [f32p, C.c_uint32, u32p]
+    L.sots_or_draw_unit.argtypes = [C.c_uint32]
+    L.sots_or_draw_unit.restype = C.c_float
+    L.sots_or_mutate_gene.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, u32p]
     L.sots_or_es_create.argtypes = [C.POINTER(Config)]
     L.sots_or_es_create.restype = C.c_void_p
     L.sots_or_es_destroy.argtypes = [C.c_void_p]
@@ -131,6 +135,14 @@ def synth(kind, values, pmin, pmax, n, table=None):
     return out
 
 
+def synth_ocl(kind, values, pmin, pmax, n, table_padded, contract):
+    """one individual with the arithmetic of the reference's OpenCL kernels (table_padded: W + 1 entries)"""
+    assert len(table_padded) >= WAVETABLE_SIZE + 1
+    out = np.zeros(n, np.float32)
+    lib().sots_or_synth_ocl(kind, _f32(values), pad_params(pmin), pad_params(pmax), _f32(table_padded), n, out, contract)
+    return out
+
+
 def spectrum(audio, win=None, wf=None):
     n = len(audio)
     if win is None:
@@ -174,6 +186,17 @@ def mutate(v, s, seed, gid_base, generation):
     p, d = v.shape
     lib().sots_or_mutate(v, s, p, d, seed, gid_base, generation)
     return v, s
+
+
+def draw_unit(word):
+    return np.float32(lib().sots_or_draw_unit(int(word) & 0xFFFFFFFF))
+
+
+def mutate_gene(value, step, d, words):
+    """(new value, new step) of one gene from the 13 random words its mutation consumes"""
+    v, s = C.c_float(float(value)), C.c_float(float(step))
+    lib().sots_or_mutate_gene(C.byref(v), C.byref(s), d, np.ascontiguousarray(words, dtype=np.uint32))
+    return np.float32(v.value), np.float32(s.value)
 
 
 def sort_perm(fit):

@@ -215,6 +215,92 @@ void sots_or_synth(uint32_t kind, const float *values, const float *pmin, const 
     }
 }
 
+/* The three voices with the arithmetic of the reference's OpenCL kernels (ocl_program.cl:280-443) instead of its CPU
+ * path's: there the sample-rate ratio is the DOUBLE expression (WAVETABLE_SIZE / 44100.0), so an increment is a double
+ * product rounded to float once (:308, :356, :417) and a modulated phase advances by a double multiply-add rounded to
+ * float once (:319, :364, :368, :425); the 3-op voice's second offset is params[4] (:363; the CPU path: params[5]);
+ * the index is the bare (uint) conversion (here: saturating, as the device converts), so a phase that lands on W reads
+ * entry W - `table` must hold W + 1 entries.  `contract`: bit 0 - the float multiply-adds are fused, bit 1 - the double
+ * ones are (OpenCL C lets the compiler contract; tests/test_ocl_reference.py finds which the compiled kernels did).
+ * Only there to explain, bit for bit, what separates sots_or_synth from the reference's device kernels. */
+static inline float ocl_tab(const float *table, float pos)
+{
+    if (!(pos > 0.0f)) return table[0];
+    if (pos >= 4294967296.0f) return table[SOTS_OR_WAVETABLE_SIZE];
+    const uint32_t i = (uint32_t)pos;
+    return table[i > SOTS_OR_WAVETABLE_SIZE ? SOTS_OR_WAVETABLE_SIZE : i];
+}
+static inline float ocl_mad(float a, float b, float c, uint32_t contract) { return (contract & 1u) ? fmaf(a, b, c) : a * b + c; }
+static inline float ocl_advance(float pos, float cur, uint32_t contract)
+{
+    const double cd = SOTS_OR_WAVETABLE_SIZE / 44100.0;
+    return (contract & 2u) ? (float)fma(cd, (double)cur, (double)pos) : (float)((double)pos + cd * (double)cur);
+}
+void sots_or_synth_ocl(uint32_t kind, const float *values, const float *pmin, const float *pmax,
+                       const float *table, uint32_t n, float *audio, uint32_t contract)
+{
+    const float wsize = (float)SOTS_OR_WAVETABLE_SIZE;
+    const double cd = SOTS_OR_WAVETABLE_SIZE / 44100.0;
+    float p[SOTS_OR_MAX_DIMS];
+    const uint32_t d = sots_or_synth_dims(kind);
+    for (uint32_t i = 0; i < d; ++i) p[i] = ocl_mad(values[i], pmax[i] - pmin[i], pmin[i], contract); /* :296, :348, :405 */
+    if (kind == SOTS_OR_SYNTH_2OP) {
+        const float mod = p[0] * p[1], fc = p[2], amp = p[3];
+        const float inc1 = (float)(cd * (double)p[0]);
+        float pos1 = 0.0f, pos2 = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float cur = ocl_mad(ocl_tab(table, pos1), mod, fc, contract);
+            audio[i] = ocl_tab(table, pos2) * amp;
+            pos1 += inc1;
+            pos2 = ocl_advance(pos2, cur, contract);
+            WRAP_HI(pos1);   /* (:322-323: no lower wrap for the first phase) */
+            WRAP_HI(pos2);
+            WRAP_LO(pos2);
+        }
+    } else if (kind == SOTS_OR_SYNTH_3OP_SERIES) {
+        const float m1 = p[0] * p[1], m2 = p[2] * p[3], m3 = p[4] * p[5];
+        const float inc1 = (float)(cd * (double)p[1]);
+        float pos1 = 0.0f, pos2 = 0.0f, pos3 = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float cur1 = ocl_mad(ocl_tab(table, pos1), m1, p[3], contract);
+            pos1 += inc1;
+            const float cur2 = ocl_mad(ocl_tab(table, pos2), m2, p[4], contract);
+            pos2 = ocl_advance(pos2, cur1, contract);
+            audio[i] = ocl_tab(table, pos3) * m3;
+            pos3 = ocl_advance(pos3, cur2, contract);
+            WRAP_HI(pos1);
+            WRAP_LO(pos1);
+            WRAP_HI(pos2);
+            WRAP_LO(pos2);
+            WRAP_HI(pos3);
+            WRAP_LO(pos3);
+        }
+    } else if (kind == SOTS_OR_SYNTH_TRIPLE_PAR) {
+        float mod[3], fc[3], amp[3], inc[3], pa[3] = { 0, 0, 0 }, pb[3] = { 0, 0, 0 };
+        for (int j = 0; j < 3; ++j) {
+            mod[j] = p[4 * j + 0] * p[4 * j + 1];
+            fc[j] = p[4 * j + 2];
+            amp[j] = p[4 * j + 3];
+            inc[j] = (float)(cd * (double)p[4 * j + 0]);
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            float tot[3];
+            for (int j = 0; j < 3; ++j) {
+                const float cur = ocl_mad(ocl_tab(table, pa[j]), mod[j], fc[j], contract);
+                tot[j] = ocl_tab(table, pb[j]) * amp[j];
+                pa[j] += inc[j];
+                pb[j] = ocl_advance(pb[j], cur, contract);
+                WRAP_HI(pa[j]);
+                WRAP_HI(pb[j]);
+                WRAP_LO(pb[j]);
+            }
+            audio[i] = (float)((double)(tot[0] + tot[1] + tot[2]) / 3.0);
+        }
+    } else {
+        for (uint32_t i = 0; i < n; ++i) audio[i] = 0.0f; /* (no OpenCL kernel for the build-defined 4-op voice) */
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* fp64 real FFT (stands in for FFTW's fftw_plan_dft_r2c_1d,                 */
 /* Evolutionary_Strategy.hpp:286,511: a forward real DFT is mathematically   */
@@ -399,8 +485,12 @@ void sots_or_recombine(const float *vin, const float *sin_, float *vout, float *
     }
 }
 
-void sots_or_mutate(float *values, float *steps, uint32_t p, uint32_t d,
-                    uint64_t seed, uint32_t gid_base, uint32_t generation)
+float sots_or_draw_unit(uint32_t word) { return draw_unit(word); }
+
+/* One gene's mutation from the 13 random words the rule consumes (ocl_program.cl:168-188): words[0] is the coin,
+ * words[1..12] make the "gaussian" (gauss_rand, :21-31).  sots_or_mutate below draws the words from the counter-based
+ * generator; tests hand in the reference's MWC64X words to compare the RULE with the reference's kernel. */
+void sots_or_mutate_gene(float *value, float *step, uint32_t d, const uint32_t words[13])
 {
     /* constants: Evolutionary_Strategy.hpp:611-627 */
     const float mpi = (float)3.14159265358979323846;
@@ -409,28 +499,34 @@ void sots_or_mutate(float *values, float *steps, uint32_t p, uint32_t d,
     const float root_two_over_pi = sqrtf(2.f / (float)mpi);
     const float beta_scale = 1.f / (float)d;
     const float beta = sqrtf(beta_scale);
+    const float ek = (words[0] % 2u == 0u) ? alpha : one_over_alpha;
+    float s = *step;
+    const float x = *value;
+    float sum = 0.0f;
+    for (uint32_t t = 0; t < 12; ++t) sum += draw_unit(words[1 + t]);
+    sum /= 12.0f;
+    float gauss = sum;
+    float new_x = x + ek * s * gauss;
+    if (new_x < 0.0f || new_x > 1.0f) {
+        gauss = gauss * -0.5f;
+        new_x = x + ek * s * gauss;
+    }
+    const float es = expf(fabsf(gauss) - root_two_over_pi);
+    s *= powf(ek, beta) * powf(es, beta_scale);
+    *step = s;
+    *value = new_x;
+}
+
+void sots_or_mutate(float *values, float *steps, uint32_t p, uint32_t d,
+                    uint64_t seed, uint32_t gid_base, uint32_t generation)
+{
     for (uint32_t i = 0; i < p; ++i)
         for (uint32_t j = 0; j < d; ++j) {
-            /* ocl_program.cl:168-188; 13 draws per gene */
-            const uint32_t base = j * 16u;
-            const uint32_t w0 = draw_word(seed, gid_base + i, generation, base, SOTS_OR_TAG_MUTATE);
-            const float ek = (w0 % 2u == 0u) ? alpha : one_over_alpha;
-            float s = steps[(size_t)i * d + j];
-            const float x = values[(size_t)i * d + j];
-            float sum = 0.0f;
-            for (uint32_t t = 0; t < 12; ++t)
-                sum += draw_unit(draw_word(seed, gid_base + i, generation, base + 1 + t, SOTS_OR_TAG_MUTATE));
-            sum /= 12.0f;
-            float gauss = sum;
-            float new_x = x + ek * s * gauss;
-            if (new_x < 0.0f || new_x > 1.0f) {
-                gauss = gauss * -0.5f;
-                new_x = x + ek * s * gauss;
-            }
-            const float es = expf(fabsf(gauss) - root_two_over_pi);
-            s *= powf(ek, beta) * powf(es, beta_scale);
-            steps[(size_t)i * d + j] = s;
-            values[(size_t)i * d + j] = new_x;
+            /* 13 draws per gene, at counter indices 16 j .. 16 j + 12 */
+            uint32_t words[13];
+            for (uint32_t t = 0; t < 13; ++t)
+                words[t] = draw_word(seed, gid_base + i, generation, j * 16u + t, SOTS_OR_TAG_MUTATE);
+            sots_or_mutate_gene(&values[(size_t)i * d + j], &steps[(size_t)i * d + j], d, words);
         }
 }
 

@@ -71,6 +71,13 @@ void sots_or_init_population(float *values, float *steps, uint32_t p, uint32_t d
 /* ocl_program.cl:73-149, race-free (all reads precede all writes): in -> out */
 void sots_or_recombine(const float *vin, const float *sin_, float *vout, float *sout,
                        uint32_t p, uint32_t d, uint32_t num_parents, uint32_t block);
+/* the voices with the arithmetic of the reference's OpenCL kernels (ocl_program.cl:280-443; double sample-rate ratio,
+ * bare index conversion: `table` holds W + 1 entries); contract bit 0 / 1: fused float / double multiply-adds */
+void sots_or_synth_ocl(uint32_t kind, const float *values, const float *pmin, const float *pmax,
+                       const float *table, uint32_t n, float *audio, uint32_t contract);
+/* the [-1, 1] float of one random word (ocl_program.cl:60, :27) and one gene's mutation from its 13 words */
+float sots_or_draw_unit(uint32_t word);
+void sots_or_mutate_gene(float *value, float *step, uint32_t d, const uint32_t words[13]);
 /* ocl_program.cl:155-190, in place */
 void sots_or_mutate(float *values, float *steps, uint32_t p, uint32_t d,
                     uint64_t seed, uint32_t gid_base, uint32_t generation);

@@ -1,0 +1,292 @@
+"""The oracle - and through it the HIP path - against the REFERENCE'S OWN device kernels.
+
+tests/golden/ocl_ref_v1.npz holds inputs and outputs of /root/reference/kernels/ocl_program.cl, compiled as it stands
+(oracle/build_ref_ocl.py: the image's clang in OpenCL C mode with the macro list of Evolutionary_Strategy_OpenCL.hpp:89-105)
+and run on an MI355X through the HIP module API (tests/golden/make_ocl_golden.py).  The file holds data only.
+
+What the vectors pin (CPU tests, `-m "not gpu"`), row of SURVEY 8(a) by row:
+  a2  initPopulation     bit-exact, given the kernel's MWC64X words (restated below: the product draws its words from a
+                         counter-based generator instead, deviation 6 of DESIGN 6)
+  a3  recombinePopulation  bit-exact where the reference kernel is race-free; it recombines IN PLACE, so an offspring block
+                         can read a parent block another workgroup has already overwritten (the runs that made the
+                         vectors disagree with each other): every element must be what the original OR the overwritten
+                         parent block yields, and the parent blocks themselves what the original yields
+  a4  mutatePopulation   the rule, given the 13 MWC64X words of a gene: values within 1 ulp (the OpenCL build fuses
+                         x + Ek s g), steps within 1e-6 relative (device exp/pow)
+  a5-a7 synthesis        oracle.synth_ocl - the voices restated with the OpenCL kernels' arithmetic (double sample-rate
+                         ratio, fused multiply-add) - is BIT-IDENTICAL to the reference's kernels on every row; the
+                         oracle proper follows the reference's CPU path (fp32 ratio) and stays within a few table steps
+  a8  applyWindow        the kernel multiplies by an fp32 cos of arguments up to 2 pi N: 3.6e-4 off the exact window at
+                         N = 1024, 1.5e-3 at N = 4096 (deviation 5: the oracle and the product use the exact table)
+  a10 fitnessPopulation  2e-7 relative with exact macros; 7e-4 ... 9e-4 with the six-decimal "%f" macros the
+                         reference's host really passes (FFT_ONE_OVER_SIZE = 0.000977 for 1/1024)
+  a11 sortPopulation     exact permutation on tie-free keys
+`-m gpu`: the product's stage kernels on the same inputs, through the C-ABI, and - when oracle/_ref holds the code
+objects - the reference's kernels run live beside them on fresh inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ocl_ref_v1.npz")
+# (tag, WRKGRPSIZE, D, log2 N, parents, offspring) - oracle/build_ref_ocl.py CONFIGS
+CONFIGS = [
+    ("2op_n1024_p512_wg32", 32, 4, 10, 128, 384),
+    ("2op_n4096_p256_wg64", 64, 4, 12, 64, 192),
+    ("3op_n1024_p256_wg32", 32, 6, 10, 64, 192),
+    ("triple_n1024_p256_wg32", 32, 12, 10, 64, 192),
+]
+KIND = {4: 0, 6: 1, 12: 2}
+TABLE_STEP = 2.0 * np.pi / 32768.0  # the largest change of the sine table between neighbouring entries
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(GOLDEN)
+
+
+def mwc64x(states):
+    """ocl_program.cl:5-16 on an array of (x, c) states: (result words, next states)"""
+    x, c = states[:, 0].astype(np.uint64), states[:, 1].astype(np.uint64)
+    a = np.uint64(4294883355)
+    res = (x ^ c).astype(np.uint32)
+    prod = x * a
+    xn = (prod + c) & np.uint64(0xFFFFFFFF)
+    cn = ((prod >> np.uint64(32)) + (xn < c).astype(np.uint64)) & np.uint64(0xFFFFFFFF)
+    return res, np.stack([xn, cn], axis=1).astype(np.uint32)
+
+
+def recombine_candidates(vin, vout_ref, parents, block):
+    """for every element of the reference's output: what the ORIGINAL parent block yields and what the reference's
+    own (already recombined) parent block yields"""
+    p, d = vin.shape
+    npb = max(parents // block, 1)
+    orig, late = np.empty_like(vin), np.empty_like(vin)
+    for b in range(p // block):
+        pb = b % npb
+        for g in range(d):
+            dst = (np.arange(block) + g * (b + 1)) % block
+            orig[b * block + dst, g] = vin[pb * block: (pb + 1) * block, g]
+            late[b * block + dst, g] = vout_ref[pb * block: (pb + 1) * block, g]
+    return orig, late
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_reference_kernels_pin_init_and_mutation_rule(O, G, cfg):
+    tag, wg, d, log2n, parents, offspring = cfg
+    e, a = tag + "/exact/", tag + "/asrun/"
+    p = parents + offspring
+    # initPopulation: value = |unit(word)|, step = 0.1, one word per gene
+    s = G[e + "init_states"].copy()
+    vals = np.zeros((p, d), np.float32)
+    for j in range(d):
+        w, s = mwc64x(s)
+        vals[:, j] = [abs(O.draw_unit(int(x))) for x in w]
+    assert np.array_equal(vals, G[e + "init_values"])
+    assert np.all(G[e + "init_steps"] == np.float32(0.1))
+    assert np.array_equal(s, G[e + "init_states_after"])
+    # mutatePopulation: 13 words per gene (coin, 12 for the gaussian), genes in order
+    s = G[e + "mutate_states"].copy()
+    words = np.zeros((p, d, 13), np.uint32)
+    for j in range(d):
+        for t in range(13):
+            words[:, j, t], s = mwc64x(s)
+    assert np.array_equal(s, G[e + "mutate_states_after"])
+    vin, sin = G[e + "mutate_in_values"], G[e + "mutate_in_steps"]
+    ov, os_ = np.zeros_like(vin), np.zeros_like(sin)
+    for i in range(p):
+        for j in range(d):
+            ov[i, j], os_[i, j] = O.mutate_gene(vin[i, j], sin[i, j], d, words[i, j])
+    reflected = 0
+    for flavour, step_tol in ((e, 5e-7), (a, 1e-6)):  # asrun: ROOT_TWO_OVER_PI = 0.797885, ONE_OVER_ALPHA = 0.714286
+        rv, rs = G[flavour + "mutate_out_values"], G[flavour + "mutate_out_steps"]
+        assert np.abs(ov - rv).max() <= 2.0 ** -24  # one ulp below 1: the OpenCL build fuses x + (Ek s) g
+        assert (np.abs(os_ - rs) / rs).max() <= step_tol
+        reflected = int(np.sum((rv < vin) != (ov < vin)))
+        assert reflected == 0  # same branch everywhere, reflect branch included
+    assert np.sum((ov >= 0) & (ov <= 1)) > 0.9 * ov.size
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_reference_kernels_pin_recombine_and_sort(O, G, cfg):
+    tag, wg, d, log2n, parents, offspring = cfg
+    e = tag + "/exact/"
+    vin, sin = G[e + "recombine_in_values"], G[e + "recombine_in_steps"]
+    rv, rs = G[e + "recombine_out_values"], G[e + "recombine_out_steps"]
+    ov, os_ = O.recombine(vin, sin, parents, wg)
+    npb = parents // wg
+    # the parent blocks read and write themselves inside one wavefront: no race, always the oracle's result
+    assert np.array_equal(ov[: npb * wg], rv[: npb * wg]) and np.array_equal(os_[: npb * wg], rs[: npb * wg])
+    for mine, ref, src in ((ov, rv, vin), (os_, rs, sin)):
+        orig, late = recombine_candidates(src, ref, parents, wg)
+        assert np.array_equal(mine, orig)                    # the oracle = the race-free reading
+        assert np.all((ref == orig) | (ref == late))         # the reference: one of the two, element by element
+    # sortPopulation on tie-free keys: the same permutation
+    perm = O.sort_perm(G[e + "sort_in_fitness"])
+    assert np.array_equal(G[e + "sort_in_fitness"][perm], G[e + "sort_out_fitness"])
+    assert np.array_equal(G[e + "sort_in_values"][perm], G[e + "sort_out_values"])
+    assert np.array_equal(G[e + "sort_in_steps"][perm], G[e + "sort_out_steps"])
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_reference_synthesis_kernels_restated_bit_for_bit(O, G, cfg):
+    tag, wg, d, log2n, parents, offspring = cfg
+    e = tag + "/exact/"
+    v, ref = G[e + "synth_values"], G[e + "synth_audio"]
+    n = ref.shape[1]
+    table = np.concatenate([O.wavetable(), np.zeros(64, np.float32)])  # the vectors were made with zeros behind the table
+    pmin, pmax = G[e + "synth_pmin"], G[e + "synth_pmax"]
+    worst_steps = 0.0
+    for r in range(len(v)):
+        # the OpenCL kernels' arithmetic (double ratio, fused multiply-add): every sample identical
+        assert np.array_equal(O.synth_ocl(KIND[d], v[r], pmin, pmax, n, table, 1), ref[r]), f"row {r}"
+        # the oracle proper follows the reference's CPU path (fp32 ratio, Evolutionary_Strategy.hpp:203,368-495): the
+        # phases round differently and drift apart by table steps, never more
+        mine = O.synth(KIND[d], v[r], pmin, pmax, n)
+        amp = np.abs(ref[r]).max()
+        if amp > 0:
+            worst_steps = max(worst_steps, float(np.abs(mine - ref[r]).max() / (amp * TABLE_STEP)))
+        else:
+            assert not mine.any()
+    # measured: 2-op N = 1024 4.0 steps, N = 4096 9.0, 3-op 18.0 (its third phase integrates a modulated frequency of
+    # up to +-28160 Hz), triple 3.8
+    assert worst_steps <= (24.0 if d == 6 else 12.0)
+    # without the fused multiply-add the restatement is NOT the kernel (the test can tell the two apart)
+    assert any(not np.array_equal(O.synth_ocl(KIND[d], v[r], pmin, pmax, n, table, 0), ref[r]) for r in range(len(v)))
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_reference_kernels_pin_window_and_fitness(O, G, cfg):
+    tag, wg, d, log2n, parents, offspring = cfg
+    e, a = tag + "/exact/", tag + "/asrun/"
+    n = 1 << log2n
+    win64, wf = O.window(n)
+    win = win64.astype(np.float32)
+    # applyWindowPopulation: out = in * w_fp32, w_fp32 = 1 - cos(i mu) in float with |i mu| up to 2 pi N
+    for flavour, tol in ((e, 4.0e-4 if n == 1024 else 1.6e-3), (a, 3.1e-3)):
+        w_ref = G[flavour + "window_out"][0]  # row 0 went in as ones
+        assert np.abs(w_ref - win).max() <= tol
+        assert np.array_equal((G[e + "window_in"][1:] * w_ref).astype(np.float32), G[flavour + "window_out"][1:])
+    assert abs(wf - 1.0) <= 2e-7
+    # fitnessPopulation on materialised spectra (bins >= N/2 are zero in the vectors, so the kernel's N/2 + 3 bins -
+    # FFT_OUT_SIZE - 2 floats, ocl_program.cl:607 - add nothing to the oracle's N/2)
+    spec, tgt = G[e + "fitness_spectrum"], G[e + "fitness_target"]
+    re, im = spec[:, 0:n:2].astype(np.float64), spec[:, 1:n:2].astype(np.float64)
+    mag = (np.hypot(re, im).astype(np.float32) * np.float32(1.0 / n)).astype(np.float32)
+    mine = np.array([O.fitness(np.ascontiguousarray(m), tgt) for m in mag])
+    assert (np.abs(mine - G[e + "fitness_out"]) / G[e + "fitness_out"]).max() <= 1e-6
+    # as the reference's host really builds the program, 1/N has six decimals: 0.000977 (N = 1024), 0.000244 (N = 4096)
+    assert (np.abs(mine - G[a + "fitness_out"]) / G[a + "fitness_out"]).max() <= 1.2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the product's kernels, through the C-ABI, on the inputs the reference's kernels ran on
+# ---------------------------------------------------------------------------------------------------------------
+PMAX = {4: [3520.0, 8.0, 3520.0, 1.0], 6: [3520.0, 8.0, 3520.0, 8.0, 8.0, 8.0], 12: [3520.0, 8.0, 3520.0, 1.0] + [0.0] * 8}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_hip_stages_on_the_reference_kernels_inputs(pkg, O, G, cfg):
+    tag, wg, d, log2n, parents, offspring = cfg
+    e = tag + "/exact/"
+    p, n = parents + offspring, 1 << log2n
+    es = pkg.HipES(parents, offspring, synth_kind=KIND[d], audio_log2=log2n, param_max=PMAX[d], workgroup_size=wg)
+    try:
+        # recombine: the race-free reading of the reference's kernel
+        vin, sin = G[e + "recombine_in_values"], G[e + "recombine_in_steps"]
+        es.write_population(vin, sin, np.zeros(p, np.float32))
+        es.recombine()
+        gv, gs, _ = es.read_population()
+        for mine, ref, src in ((gv, G[e + "recombine_out_values"], vin), (gs, G[e + "recombine_out_steps"], sin)):
+            orig, late = recombine_candidates(src, ref, parents, wg)
+            assert np.array_equal(mine, orig)
+            assert np.array_equal(mine[: parents], ref[: parents])
+        # sort: the reference's rows, exactly
+        es.write_population(G[e + "sort_in_values"], G[e + "sort_in_steps"], G[e + "sort_in_fitness"])
+        es.sort(), es.rotate()
+        sv, ss, sf = es.read_population()
+        assert np.array_equal(sf, G[e + "sort_out_fitness"])
+        assert np.array_equal(sv, G[e + "sort_out_values"]) and np.array_equal(ss, G[e + "sort_out_steps"])
+        # synthesis: the CPU path's arithmetic, a few table steps from the device kernels' (see the CPU test)
+        v, ref = G[e + "synth_values"], G[e + "synth_audio"]
+        pv = np.zeros((p, d), np.float32)
+        pv[: len(v)] = v
+        es.write_population(pv, np.full((p, d), 0.1, np.float32), np.zeros(p, np.float32))
+        es.synthesise()
+        audio = es.read_audio()[: len(v)]
+        for r in range(len(v)):
+            assert np.array_equal(audio[r], O.synth(KIND[d], v[r], np.zeros(d, np.float32), np.array(PMAX[d], np.float32), n))
+            amp = np.abs(ref[r]).max()
+            assert np.abs(audio[r] - ref[r]).max() <= (24.0 if d == 6 else 12.0) * TABLE_STEP * amp
+        # window: the exact table against the kernel's fp32 cos
+        aud = np.zeros((p, n), np.float32)
+        aud[:3] = G[e + "window_in"]
+        es.write_audio(aud)
+        es.window()
+        got = es.read_audio()[:3]
+        tol = 4.0e-4 if n == 1024 else 1.6e-3
+        assert np.abs(got - G[e + "window_out"]).max() <= tol * np.abs(G[e + "window_in"]).max()
+        # fitness on the materialised spectra
+        spec, tgt = G[e + "fitness_spectrum"], G[e + "fitness_target"]
+        rows = np.zeros((p, n + 8), np.float32)
+        rows[: len(spec)] = spec
+        es.set_target_spectrum(tgt)
+        es.write_spectrum(rows)
+        es.fitness()
+        fit = es.read_fitness()[: len(spec)]
+        assert (np.abs(fit - G[e + "fitness_out"]) / G[e + "fitness_out"]).max() <= 1e-4
+    finally:
+        es.close()
+
+
+@pytest.mark.gpu
+def test_reference_kernels_run_live_beside_the_hip_kernels(pkg, O):
+    """Fresh inputs (not the golden ones): the reference's sort and 2-op synthesis kernels, launched here from the code
+    objects the build container compiled, against the product and the restatement."""
+    import _ocl_ref as R
+    tag, wg, d, log2n, parents, offspring = CONFIGS[0]
+    if not os.path.exists(R.code_object(tag, "exact")):
+        pytest.skip("oracle/_ref holds no code objects (python oracle/build_ref_ocl.py needs /root/reference)")
+    p, n = parents + offspring, 1 << log2n
+    rng = np.random.default_rng(20261005)
+    prog = R.RefProgram(tag, "exact")
+    rot = R.DeviceBuffer(np.zeros(1, np.uint32))
+    es = pkg.HipES(parents, offspring, synth_kind=0, audio_log2=log2n, param_max=PMAX[4], workgroup_size=wg)
+    try:
+        fit = np.zeros((2, p), np.float32)
+        fit[0] = (rng.permutation(p).astype(np.float32) * np.float32(0.01) + np.float32(0.001)) ** 2
+        sv, ss = rng.random((2, p, d), dtype=np.float32), rng.random((2, p, d), dtype=np.float32)
+        bv, bs, bf = R.DeviceBuffer(sv), R.DeviceBuffer(ss), R.DeviceBuffer(fit)
+        prog.launch("sortPopulation", p, wg, [bv, bs, bf, rot])
+        es.write_population(sv[0], ss[0], fit[0])
+        es.sort(), es.rotate()
+        gv, gs, gf = es.read_population()
+        assert np.array_equal(gf, bf.read(np.float32, (2, p))[1])
+        assert np.array_equal(gv, bv.read(np.float32, (2, p, d))[1]) and np.array_equal(gs, bs.read(np.float32, (2, p, d))[1])
+        for b in (bv, bs, bf):
+            b.free()
+        pv = np.zeros((2, p, d), np.float32)
+        pv[0] = rng.random((p, d), dtype=np.float32)
+        table = np.concatenate([O.wavetable(), np.zeros(64, np.float32)])
+        baud, bv = R.DeviceBuffer(nbytes=p * n * 4), R.DeviceBuffer(pv)
+        bmin, bmax, btab = R.DeviceBuffer(np.zeros(d, np.float32)), R.DeviceBuffer(np.array(PMAX[4], np.float32)), R.DeviceBuffer(table)
+        prog.launch("synthesisePopulation", p, wg, [baud, bv, bmin, bmax, rot, btab])
+        ref = baud.read(np.float32, (p, n))
+        es.write_population(pv[0], np.full((p, d), 0.1, np.float32), np.zeros(p, np.float32))
+        es.synthesise()
+        audio = es.read_audio()
+        # the product runs the CPU path's fp32 arithmetic, the kernel the double ratio: table steps apart, more where a
+        # large modulation index amplifies the phase difference (these 512 rows: median 1.0, 90 % below 2.0, worst 20.7)
+        amp = np.abs(ref).max(axis=1)
+        steps = np.abs(audio - ref).max(axis=1) / (amp * TABLE_STEP)
+        assert np.median(steps) <= 2.0 and np.percentile(steps, 90) <= 4.0 and steps.max() <= 48.0
+        for r in range(0, p, 37):
+            assert np.array_equal(O.synth_ocl(0, pv[0, r], np.zeros(d, np.float32), np.array(PMAX[4], np.float32), n, table, 1), ref[r])
+        for b in (baud, bv, bmin, bmax, btab):
+            b.free()
+    finally:
+        es.close()
+        rot.free()
+        prog.unload()
