@@ -33,6 +33,10 @@ CONFIGS = [
     ("2op_n4096_p256_wg64", 64, 4, 12, 64, 192),
     ("3op_n1024_p256_wg32", 32, 6, 10, 64, 192),
     ("triple_n1024_p256_wg32", 32, 12, 10, 64, 192),
+    # BASELINE configs[1]: the free-running loop of tests/test_gpu_statistical.py
+    ("2op_n1024_p1024_wg32", 32, 4, 10, 256, 768),
+    # BASELINE configs[2] at the reference's shipped workgroup size (parameters.json:31): only timed (tests/ref_kernels_time.py)
+    ("2op_n1024_p65536_wg32", 32, 4, 10, 16384, 49152),
 ]
 
 
