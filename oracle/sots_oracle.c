@@ -1,9 +1,10 @@
 /*
  * sots_oracle.c -- CPU restatement of the reference's per-generation hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see sots_oracle.h).  PARITY UNPINNED by the
- * reference itself: it holds no fixtures for this path and cannot be built
- * here.  Compile with -O2 -ffp-contract=off (the Makefile does): every fp32
+ * TEST INFRASTRUCTURE ONLY (see sots_oracle.h, which also says what pins it: since
+ * round 4 the reference's own device kernels, compiled as they stand and run on
+ * the GPU - tests/test_ocl_reference.py; its CPU host path cannot be built
+ * here).  Compile with -O2 -ffp-contract=off (the Makefile does): every fp32
  * expression below is meant to round exactly as written.
  *
  * Deliberate deviations from the reference's (defective) CPU code, SURVEY 8c:

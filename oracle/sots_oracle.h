@@ -5,15 +5,18 @@
  * C++ host wrapper, the Python binding) may include, link or call this file.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
  *
- * PARITY UNPINNED: the reference ships no golden vectors, known-answer tests or
- * fixtures for this path, all of its RNG seeding
- * is wall-clock, and its own CPU path cannot be compiled in this image
- * (Evolutionary_Strategy.hpp:11 needs fftw_cpp.hh; fftw3, glm, sndfile are
- * absent).  The restatement below is therefore pinned only by (a) an
- * independent NumPy restatement (tests/golden/make_golden.py), (b) a naive
- * O(N^2) DFT, (c) the published Random123 Philox4x32-10 known-answer vectors,
- * (d) the self-match property the reference's own debug constants imply
- * (ocl_program.cl:247-250: fitness(true parameters) == 0).
+ * PARITY: pinned, stage by stage, by the reference's OWN DEVICE KERNELS since round 4 - kernels/ocl_program.cl
+ * compiled as it stands for gfx950 (oracle/build_ref_ocl.py -> code objects under oracle/_ref), run on an MI355X through the HIP
+ * module API, inputs and outputs committed as tests/golden/ocl_ref_v1.npz (tests/test_ocl_reference.py): init,
+ * mutation rule (given the kernel's MWC64X words), recombination (the race-free reading of an in-place kernel),
+ * the three voices (sots_or_synth_ocl restates the kernels' arithmetic bit for bit; sots_or_synth follows the
+ * reference's CPU path - fp32 sample-rate ratio - and stays within table steps of it), window (to the kernel's own fp32
+ * cosine error), fitness, sort.  STILL UNPINNED by the reference: its CPU host path (Evolutionary_Strategy.hpp:11 needs
+ * fftw_cpp.hh; fftw3, glm, sndfile are absent, nothing was stubbed), the FFT (clFFT / FFTW are third-party and absent:
+ * a forward real DFT is fixed mathematically; fp64 FFT against a naive O(N^2) DFT and NumPy), the build-defined 4-op
+ * voice (no reference row), and the random streams (the reference seeds from the wall clock).  Further pins: an
+ * independent NumPy restatement (tests/golden/make_golden.py), the published Random123 Philox4x32-10 known answers,
+ * the self-match property the reference's debug constants imply (ocl_program.cl:247-250).
  *
  * All file:line citations are relative to /root/reference.
  */

@@ -18,7 +18,8 @@ statistics came out at 0.035 dex, 0.28 and 0.03:
     two-sample Kolmogorov-Smirnov distance of log10(best fitness) <= KS_MAX = 0.41 (the alpha = 0.01
     critical value for 32 + 32 samples is 0.407);
   * generation 100: the fractions of seeds below 1e-3 (converged to the target's basin) within 6/32.
-Parity stays "unpinned" in the sense of DESIGN.md 6 (the oracle is this repository's restatement)."""
+The second test below runs the same comparison against the REFERENCE'S OWN generation loop (its kernels, compiled as
+they stand; numpy in place of clFFT)."""
 import numpy as np
 import pytest
 

@@ -1,8 +1,9 @@
 """CPU tests of the oracle (oracle/sots_oracle.c) against the committed golden vectors
 (tests/golden/golden_v1.npz, produced by the independent NumPy restatement in
 tests/golden/make_golden.py), the Random123 Philox known answers, a naive DFT and the
-self-match property.  PARITY UNPINNED by the reference itself: it ships no fixtures for
-this path, so these are the pins.
+self-match property.  The reference ships no fixtures for this path; these pins are this
+repository's own.  The pins that come from the reference itself - outputs of its device kernels, compiled as they stand
+and run on an MI355X - are in tests/test_ocl_reference.py.
 """
 import os
 
