@@ -290,3 +290,71 @@ def test_reference_kernels_run_live_beside_the_hip_kernels(pkg, O):
         es.close()
         rot.free()
         prog.unload()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CONFIGS[1:], ids=[c[0] for c in CONFIGS[1:]])
+def test_reference_voices_live_with_unconstrained_rows(pkg, O, cfg):
+    """Every voice kernel on fresh, unconstrained parameter rows (the 3-op rows of the golden file keep values[4] == values[5]):
+    the restatement with the kernels' arithmetic - including the OpenCL 3-op voice's params[4] offset (ocl_program.cl:363; the CPU
+    path and the product: params[5]) - is bit-identical to the kernel on every row."""
+    import _ocl_ref as R
+    tag, wg, d, log2n, parents, offspring = cfg
+    if not os.path.exists(R.code_object(tag, "exact")):
+        pytest.skip("oracle/_ref holds no code objects (python oracle/build_ref_ocl.py needs /root/reference)")
+    p, n = parents + offspring, 1 << log2n
+    rng = np.random.default_rng(31 + d)
+    pmax = np.array({4: [3520, 8, 3520, 1], 6: [3520, 8, 3520, 8, 3520, 8], 12: [3520, 8, 3520, 1] * 3}[d], np.float32)
+    pv = np.zeros((2, p, d), np.float32)
+    pv[0] = rng.random((p, d), dtype=np.float32)
+    table = np.concatenate([O.wavetable(), np.zeros(64, np.float32)])
+    prog = R.RefProgram(tag, "exact")
+    bufs = [R.DeviceBuffer(nbytes=p * n * 4), R.DeviceBuffer(pv), R.DeviceBuffer(np.zeros(d, np.float32)), R.DeviceBuffer(pmax),
+            R.DeviceBuffer(np.zeros(1, np.uint32)), R.DeviceBuffer(table)]
+    try:
+        prog.launch(R.RefGenerationLoop.SYNTH[d], p, wg, bufs)
+        ref = bufs[0].read(np.float32, (p, n))
+        for r in range(p):
+            assert np.array_equal(O.synth_ocl(KIND[d], pv[0, r], np.zeros(d, np.float32), pmax, n, table, 1), ref[r]), f"row {r}"
+        if d == 6:  # the two backends of the reference are different voices here: params[4] (Hz, up to 3520) against params[5] (index, up to 8)
+            mine = np.stack([O.synth(1, pv[0, r], np.zeros(d, np.float32), pmax, n) for r in range(16)])
+            assert np.abs(mine - ref[:16]).max() > 1.0
+    finally:
+        for b in bufs:
+            b.free()
+        prog.unload()
+
+
+@pytest.mark.gpu
+def test_reference_sort_kernel_live_with_ties(pkg, O):
+    """Equal fitness values: the reference's rank sort puts the HIGHER original index first (ocl_program.cl:698-699), its CPU
+    path's stable bubble sort the lower one (Evolutionary_Strategy.hpp:108-124).  The product follows the CPU path."""
+    import _ocl_ref as R
+    tag, wg, d, log2n, parents, offspring = CONFIGS[0]
+    if not os.path.exists(R.code_object(tag, "exact")):
+        pytest.skip("oracle/_ref holds no code objects (python oracle/build_ref_ocl.py needs /root/reference)")
+    p = parents + offspring
+    rng = np.random.default_rng(5)
+    fit = np.zeros((2, p), np.float32)
+    fit[0] = rng.integers(0, 40, size=p).astype(np.float32) * np.float32(0.25)  # about 13 rows per value
+    sv, ss = rng.random((2, p, d), dtype=np.float32), rng.random((2, p, d), dtype=np.float32)
+    prog = R.RefProgram(tag, "exact")
+    bufs = [R.DeviceBuffer(sv), R.DeviceBuffer(ss), R.DeviceBuffer(fit), R.DeviceBuffer(np.zeros(1, np.uint32))]
+    es = pkg.HipES(parents, offspring, synth_kind=0, audio_log2=log2n, param_max=PMAX[4], workgroup_size=wg)
+    try:
+        prog.launch("sortPopulation", p, wg, bufs)
+        idx = np.arange(p)
+        high_first = np.lexsort((-idx, fit[0]))
+        low_first = np.lexsort((idx, fit[0]))
+        assert np.array_equal(bufs[2].read(np.float32, (2, p))[1], fit[0][high_first])
+        assert np.array_equal(bufs[0].read(np.float32, (2, p, d))[1], sv[0][high_first])
+        es.write_population(sv[0], ss[0], fit[0])
+        es.sort(), es.rotate()
+        gv, gs, gf = es.read_population()
+        assert np.array_equal(gv, sv[0][low_first]) and np.array_equal(gs, ss[0][low_first]) and np.array_equal(gf, fit[0][low_first])
+        assert np.array_equal(low_first, O.sort_perm(fit[0]))
+    finally:
+        es.close()
+        for b in bufs:
+            b.free()
+        prog.unload()
