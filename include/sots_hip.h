@@ -86,6 +86,17 @@ enum sots_sort_mode {
                               * than S elites fails with SOTS_ERR_STATE) */
 };
 
+/* Which of the reference's two arithmetics synthesisePopulation uses.  Its CPU path (Evolutionary_Strategy.hpp:203,368-495)
+ * keeps the sample-rate ratio in fp32; its device kernels (ocl_program.cl:280-443) write it as a double expression, fuse
+ * their multiply-adds and, in the 3-op voice, add params[4] where the CPU path adds params[5]: the same parameters give
+ * audio a few wavetable steps apart.  north_star names the CPU path as the parity target: the default,
+ * and what every tuned kernel computes. */
+enum sots_synth_arith {
+    SOTS_ARITH_CPU_PATH = 0,
+    SOTS_ARITH_DEVICE_KERNELS = 1 /* bit-identical to the reference's OpenCL kernels as compiled for this GPU
+                                   * (tests/test_ocl_reference.py); one plain kernel, not tuned; not for the 4-op voice */
+};
+
 /* Replaces Evolutionary_Strategy_OpenCL_Arguments
  * (Evolutionary_Strategy_OpenCL.hpp:25-38) + Evolutionary_Strategy_Arguments
  * (Evolutionary_Strategy.hpp:579-589). */
@@ -172,6 +183,9 @@ int sots_execute_generation(sots_ctx *ctx);
 int sots_execute_generations(sots_ctx *ctx, uint32_t n);
 
 int sots_set_sort_mode(sots_ctx *ctx, uint32_t mode); /* enum sots_sort_mode */
+/* enum sots_synth_arith; applies to sots_stage_synthesise and to both generation loops from the next call on
+ * (replaces nothing: the reference picks its arithmetic by picking a backend, main.cpp:105-163) */
+int sots_set_synth_arithmetic(sots_ctx *ctx, uint32_t arith);
 int sots_get_generation(const sots_ctx *ctx, uint32_t *generation);
 int sots_set_generation(sots_ctx *ctx, uint32_t generation);
 

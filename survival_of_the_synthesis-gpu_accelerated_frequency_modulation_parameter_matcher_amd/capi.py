@@ -26,6 +26,7 @@ SYNTH_NAMES = {"2op": SYNTH_2OP, "3op_series": SYNTH_3OP_SERIES,
  STAGE_FITNESS, STAGE_SORT, STAGE_ROTATE, STAGE_FUSED_VARIATION, STAGE_FUSED_SYNTH,
  STAGE_FUSED_SPECTRAL, STAGE_SORT_TAIL, STAGE_COUNT) = range(14)
 SORT_LAZY_TAIL, SORT_FULL, SORT_TOP_ONLY = 0, 1, 2
+ARITH_CPU_PATH, ARITH_DEVICE_KERNELS = 0, 1
 
 # the reference's Benchmarker timer names, Evolutionary_Strategy_OpenCL.hpp:117
 STAGE_NAMES = ["initPopulation", "recombinePopulation", "mutatePopulation", "synthesisePopulation",
@@ -41,6 +42,7 @@ EXPORTS = [
     "sots_stage_recombine", "sots_stage_mutate", "sots_stage_synthesise", "sots_stage_window",
     "sots_stage_fft", "sots_stage_fitness", "sots_stage_sort", "sots_stage_select", "sots_stage_rotate",
     "sots_set_sort_mode",
+    "sots_set_synth_arithmetic",
     "sots_execute_generation", "sots_execute_generations", "sots_get_generation",
     "sots_set_generation", "sots_timing_enable", "sots_timing_reset", "sots_stage_time_ms",
     "sots_stage_launch_times_ms",
@@ -111,6 +113,7 @@ def load():
     L.sots_write_synth.argtypes = [vp, vp, sz, vp, sz]
     L.sots_read_synth.argtypes = [vp, vp, sz, vp, sz, vp, sz]
     L.sots_set_sort_mode.argtypes = [vp, u32]
+    L.sots_set_synth_arithmetic.argtypes = [vp, u32]
     for name in ("recombine", "mutate", "synthesise", "window", "fft", "fitness", "sort", "select", "rotate"):
         getattr(L, "sots_stage_" + name).argtypes = [vp]
     L.sots_execute_generation.argtypes = [vp]
@@ -334,6 +337,10 @@ class HipES:
 
     def set_sort_mode(self, mode):
         self._check(self.L.sots_set_sort_mode(self._h, mode))
+
+    def set_synth_arithmetic(self, arith):
+        """ARITH_CPU_PATH (default) or ARITH_DEVICE_KERNELS: the reference's OpenCL kernels' arithmetic (enum sots_synth_arith)"""
+        self._check(self.L.sots_set_synth_arithmetic(self._h, arith))
 
     def execute_generation(self):
         self._check(self.L.sots_execute_generation(self._h))

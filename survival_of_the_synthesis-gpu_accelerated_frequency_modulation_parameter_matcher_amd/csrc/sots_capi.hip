@@ -60,6 +60,7 @@ struct sots_ctx {
     // selection state: after the fused loop's partial sort only rows [0, tail_first) of the current half
     // are in place; the unsorted half it came from is intact until the next generation starts
     uint32_t sort_mode = SOTS_SORT_LAZY_TAIL;
+    uint32_t synth_arith = SOTS_ARITH_CPU_PATH;
     bool tail_pending = false;
     uint32_t tail_first = 0;
     // island exchange folded into the sort of the last generation of the next sots_execute_generations call
@@ -625,6 +626,10 @@ int sots_stage_synthesise(sots_ctx *ctx)
     if (int rc = bind_device(ctx)) return rc;
     {
         StageScope t(ctx, SOTS_STAGE_SYNTHESISE);
+        if (ctx->synth_arith == SOTS_ARITH_DEVICE_KERNELS)
+            SOTS_HIP(ctx, launch_synth_device_arith(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, ctx->audio,
+                                                    ctx->sp, ctx->P, ctx->log2n, ctx->pitch));
+        else
         SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable,
                                    ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus, nullptr, ctx->allow_cut));
     }
@@ -756,7 +761,8 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
         // Large populations of 4-gene individuals make their individuals inside the synthesis kernel
         // (one launch less, 151 vs 157 us per generation at P = 65536); with few wavefronts per CU or
         // more genes the serial per-lane variation costs more than the launch it saves (measured).
-        const bool fuse_variation = ctx->fuse_variation >= 0 ? ctx->fuse_variation == 1
+        const bool device_arith = ctx->synth_arith == SOTS_ARITH_DEVICE_KERNELS; // (compatibility kernel: makes no individuals)
+        const bool fuse_variation = device_arith ? false : ctx->fuse_variation >= 0 ? ctx->fuse_variation == 1
                                                              : (ctx->pd.d <= 4 && ctx->P >= 192u * (ctx->num_cus ? ctx->num_cus : 256u)) ||
                                                                    // a few individuals per CU: k_synth_tp makes them, a thread per gene
                                                                    (ctx->allow_cut && synth_time_parallel(ctx->cfg.synth_kind, ctx->P, ctx->num_cus)) ||
@@ -777,6 +783,10 @@ int sots_execute_generations(sots_ctx *ctx, uint32_t n)
             // raw synthesis (the window is applied by the FFT kernel as it loads the row); by default the
             // kernel also makes its individuals: recombination + mutation from the sorted half
             sots::Variation var = {ctx->val(src), ctx->stp(src), ctx->val(dst), ctx->stp(dst), ctx->pd, ctx->mc, ctx->generation};
+            if (device_arith)
+                SOTS_HIP(ctx, launch_synth_device_arith(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable, ctx->audio,
+                                                        ctx->sp, ctx->P, ctx->log2n, ctx->pitch));
+            else
             SOTS_HIP(ctx, launch_synth(ctx->stream, ctx->cfg.synth_kind, ctx->val(ctx->rot), ctx->wavetable,
                                        ctx->audio, ctx->sp, ctx->P, ctx->log2n, ctx->pitch, ctx->num_cus,
                                        fuse_variation ? &var : nullptr, ctx->allow_cut));
@@ -824,6 +834,16 @@ int sots_set_sort_mode(sots_ctx *ctx, uint32_t mode)
     // is intact as long as the state is pending, settle_tail), entering it keeps the rows unspecified
     ctx->sort_mode = mode;
     return complete_tail(ctx);
+}
+
+int sots_set_synth_arithmetic(sots_ctx *ctx, uint32_t arith)
+{
+    SOTS_REQUIRE_CTX(ctx);
+    if (arith > SOTS_ARITH_DEVICE_KERNELS) return fail(ctx, SOTS_ERR_INVALID, "unknown synthesis arithmetic %u", arith);
+    if (arith == SOTS_ARITH_DEVICE_KERNELS && ctx->cfg.synth_kind == SOTS_SYNTH_4OP_SERIES)
+        return fail(ctx, SOTS_ERR_INVALID, "the reference has no device kernel for the build-defined 4-op voice");
+    ctx->synth_arith = arith;
+    return SOTS_OK;
 }
 
 int sots_get_generation(const sots_ctx *ctx, uint32_t *generation)

@@ -94,6 +94,9 @@ bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus);
 bool synth_operators_in_lanes(uint32_t kind, uint32_t p, uint32_t num_cus);
 // Audio rows are `pitch` floats apart (pitch >= N, a multiple of 4): a power-of-two row stride
 // would put every lane of a row-per-lane store on the same memory channel.
+// the voices with the arithmetic of the reference's device kernels (ocl_program.cl:280-443); no 4-op voice
+hipError_t launch_synth_device_arith(hipStream_t st, uint32_t kind, const float *values, const float *wavetable, float *audio,
+                                     const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch);
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
                         uint32_t num_cus, const Variation *var = nullptr, bool allow_cut = true);

@@ -3344,6 +3344,106 @@ bool synth_time_parallel(uint32_t kind, uint32_t p, uint32_t num_cus)
 #endif
 }
 
+// ------------------------------------------------------------------------------------
+// The voices with the arithmetic of the reference's DEVICE kernels (sots_set_synth_arithmetic, SOTS_ARITH_DEVICE_KERNELS):
+// ocl_program.cl:280-443 writes the sample-rate ratio as the double expression (WAVETABLE_SIZE / 44100.0), so an increment
+// is a double product rounded to float once (:308, :356, :417) and a modulated phase advances by a double multiply-add
+// rounded once (:319, :364, :368, :425); the float multiply-adds are fused by the OpenCL build; the 3-op voice's second
+// offset is params[4] (:363); the first phase of the 2-op and triple voices has no lower wrap (:322-323); the index is the
+// bare conversion, so a phase that lands on W reads entry W (here: 0 = sin 2 pi, the table's own continuation).
+// tests/test_ocl_reference.py holds the outputs of those kernels - compiled as they stand and run on this GPU - and this
+// kernel reproduces them bit for bit.  A compatibility path (a lane per individual, samples through a 64 x 16 tile so that
+// four lanes store one row's 64 bytes): nothing of BASELINE's configurations runs here.
+// ------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void k_synth_dev(const float *__restrict__ values, const float *__restrict__ wavetable,
+                                                   float *__restrict__ audio, SynthParams sp, uint32_t p_len, uint32_t n, uint32_t pitch)
+{
+    constexpr int D = VoiceShape<KIND>::D, U = 16, STRIDE = U + 1;
+    static_assert(KIND != SOTS_SYNTH_4OP_SERIES, "the reference has no device kernel for the build-defined 4-op voice");
+    __shared__ float tab[kWavetableSize + 1];
+    __shared__ float tile_all[4][kWave * STRIDE];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    for (uint32_t i = tid; i < kWavetableSize; i += 256) tab[i] = wavetable[i];
+    if (tid == 0) tab[kWavetableSize] = 0.0f;
+    const uint32_t row = blockIdx.x * 256u + tid;
+    const bool live = row < p_len;
+    float ps[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int s = KIND == SOTS_SYNTH_TRIPLE_PAR ? (i & 3) : i; // (one set of bounds for the three voices, as everywhere in this library)
+        ps[i] = __builtin_fmaf(live ? values[(size_t)row * D + i] : 0.0f, sp.pmax[s] - sp.pmin[s], sp.pmin[s]);
+    }
+    const double cd = (double)kWavetableSize / 44100.0;
+    auto at = [&](float pos) -> float {
+        uint32_t i = pos > 0.0f ? (uint32_t)pos : 0u;
+        return tab[i > kWavetableSize ? kWavetableSize : i];
+    };
+    auto advance = [&](float pos, float cur) -> float { return (float)__builtin_fma(cd, (double)cur, (double)pos); };
+    auto wrap_hi = [&](float &pos) { if (pos >= kWf) pos -= kWf; };
+    auto wrap_lo = [&](float &pos) { if (pos < 0.0f) pos += kWf; };
+    constexpr int J = KIND == SOTS_SYNTH_TRIPLE_PAR ? 3 : 1;
+    float pa[J] = {}, pb[J] = {}, pc = 0.0f, inc[J], mod[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        mod[j] = ps[4 * j + 0] * ps[4 * j + 1];
+        inc[j] = (float)(cd * (double)ps[KIND == SOTS_SYNTH_3OP_SERIES ? 1 : 4 * j]);
+    }
+    const float m2 = KIND == SOTS_SYNTH_3OP_SERIES ? ps[2] * ps[3] : 0.0f, m3 = KIND == SOTS_SYNTH_3OP_SERIES ? ps[D - 2] * ps[D - 1] : 0.0f;
+    float *const tile = tile_all[wave];
+    __syncthreads();
+    for (uint32_t s0 = 0; s0 < n; s0 += U) {
+#pragma unroll 4
+        for (int u = 0; u < U; ++u) {
+            float out;
+            if constexpr (KIND == SOTS_SYNTH_3OP_SERIES) {
+                const float cur1 = __builtin_fmaf(at(pa[0]), mod[0], ps[3]);
+                pa[0] += inc[0];
+                const float cur2 = __builtin_fmaf(at(pb[0]), m2, ps[4]);
+                pb[0] = advance(pb[0], cur1);
+                out = at(pc) * m3;
+                pc = advance(pc, cur2);
+                wrap_hi(pa[0]), wrap_lo(pa[0]), wrap_hi(pb[0]), wrap_lo(pb[0]), wrap_hi(pc), wrap_lo(pc);
+            } else {
+                float tot[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const float cur = __builtin_fmaf(at(pa[j]), mod[j], ps[4 * j + 2]);
+                    tot[j] = at(pb[j]) * ps[4 * j + 3];
+                    pa[j] += inc[j];
+                    pb[j] = advance(pb[j], cur);
+                    wrap_hi(pa[j]), wrap_hi(pb[j]), wrap_lo(pb[j]);
+                }
+                if constexpr (J == 3) out = (float)((double)(tot[0] + tot[1] + tot[2]) / 3.0);
+                else out = tot[0];
+            }
+            tile[lane * STRIDE + u] = out;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { // four lanes per row: 64 contiguous bytes
+            const uint32_t r = it * 16u + lane / 4u, c = (lane & 3u) * 4u;
+            const uint32_t grow = blockIdx.x * 256u + wave * kWave + r;
+            const float4 v = make_float4(tile[r * STRIDE + c], tile[r * STRIDE + c + 1], tile[r * STRIDE + c + 2], tile[r * STRIDE + c + 3]);
+            if (grow < p_len) *reinterpret_cast<float4 *>(audio + (size_t)grow * pitch + s0 + c) = v;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_synth_device_arith(hipStream_t st, uint32_t kind, const float *values, const float *wavetable, float *audio,
+                                     const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch)
+{
+    const uint32_t n = 1u << log2n, grid = (p + 255u) / 256u;
+    switch (kind) {
+    case SOTS_SYNTH_2OP: k_synth_dev<SOTS_SYNTH_2OP><<<grid, 256, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+    case SOTS_SYNTH_3OP_SERIES: k_synth_dev<SOTS_SYNTH_3OP_SERIES><<<grid, 256, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+    case SOTS_SYNTH_TRIPLE_PAR: k_synth_dev<SOTS_SYNTH_TRIPLE_PAR><<<grid, 256, 0, st>>>(values, wavetable, audio, sp, p, n, pitch); break;
+    default: return hipErrorInvalidValue; // (the 4-op voice is build-defined: the reference has no kernel to agree with)
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(hipStream_t st, uint32_t kind, const float *values, const float *wavetable,
                         float *audio, const SynthParams &sp, uint32_t p, uint32_t log2n, uint32_t pitch,
                         uint32_t num_cus, const Variation *variation, bool allow_cut)

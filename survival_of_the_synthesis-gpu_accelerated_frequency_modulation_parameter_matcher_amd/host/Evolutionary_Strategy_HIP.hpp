@@ -50,6 +50,10 @@ struct Evolutionary_Strategy_HIP_Arguments
     // true: sortPopulation orders all P rows every generation as the reference does; false: each generation places
     // the rows the next recombination reads and the rest of the order is produced when it is read (same results)
     bool fullSortEveryGeneration = false;
+    // false (default): the synthesis arithmetic of the reference's CPU path (fp32 sample-rate ratio, Evolutionary_Strategy.hpp:203);
+    // true: that of its OpenCL kernels (double ratio, fused multiply-adds, 3-op offset params[4]: ocl_program.cl:280-443) -
+    // bit-identical audio to those kernels, through one plain kernel (enum sots_synth_arith); not for the 4-op voice
+    bool deviceKernelArithmetic = false;
     // Island model inside this object (type.HIP.{numDevices,numElites,migrationInterval} in parameters.json;
     // the reference picks exactly one device, ...OpenCL.hpp:194-226).  es_args.pop describes ONE island; with
     // numDevices > 1 the object owns one island per device (devices[i], default deviceOrdinal + i), PRNG ids
@@ -223,6 +227,9 @@ public:
         if (args_.fullSortEveryGeneration)
             for (uint32_t i = 0; i < numIslands(); ++i)
                 check(sots_set_sort_mode(group_ ? sots_group_island(group_, i) : ctx_, SOTS_SORT_FULL), "sots_set_sort_mode");
+        if (args_.deviceKernelArithmetic)
+            for (uint32_t i = 0; i < numIslands(); ++i)
+                check(sots_set_synth_arithmetic(group_ ? sots_group_island(group_, i) : ctx_, SOTS_ARITH_DEVICE_KERNELS), "sots_set_synth_arithmetic");
         check(sots_timing_enable(ctx_, args_.benchmarkStages ? 1 : 0), "sots_timing_enable");
     }
     void initTargetAudio() override {}

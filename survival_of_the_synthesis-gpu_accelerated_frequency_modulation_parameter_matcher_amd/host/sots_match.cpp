@@ -2,7 +2,7 @@
 //     sots_match -j parameters.json
 // Reads the reference's parameters.json schema (general / audio / evolutionary / type), with
 // "type": {"implementation": "HIP", "HIP": {"workgroupSize", "device", "seed", "synth", "numDevices", "numElites",
-// "migrationInterval", "overlapMigration", "devices"}},
+// "migrationInterval", "overlapMigration", "devices", "fullSortEveryGeneration", "deviceKernelArithmetic"}},
 // builds the target from "params" (synthesised) or "audio" (a mono WAV file), matches every
 // N-sample chunk with Evolutionary_Strategy_HIP, writes inputGenerated.wav and the
 // outputAudioPath rendering of the best match, and prints the best parameters.
@@ -189,6 +189,7 @@ int main(int argc, char *argv[])
             if (h.has("migrationInterval")) args.migrationInterval = (uint32_t)h["migrationInterval"].number();
             if (h.has("overlapMigration")) args.overlapMigration = h["overlapMigration"].b;
             if (h.has("fullSortEveryGeneration")) args.fullSortEveryGeneration = h["fullSortEveryGeneration"].b;
+            if (h.has("deviceKernelArithmetic")) args.deviceKernelArithmetic = h["deviceKernelArithmetic"].b;
             if (h.has("devices"))
                 for (const Json &dv : h["devices"].arr) args.devices.push_back((int32_t)dv.number());
             if (h.has("synth")) {

@@ -358,3 +358,109 @@ def test_reference_sort_kernel_live_with_ties(pkg, O):
         for b in bufs:
             b.free()
         prog.unload()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_hip_device_kernel_arithmetic_is_the_reference_kernels_bit_for_bit(pkg, O, G, cfg):
+    """sots_set_synth_arithmetic(SOTS_ARITH_DEVICE_KERNELS): the PRODUCT's audio against the audio the reference's own
+    kernels wrote (golden file) - every sample identical.  The default arithmetic (the reference's CPU path) is not."""
+    tag, wg, d, log2n, parents, offspring = cfg
+    e = tag + "/exact/"
+    p, n = parents + offspring, 1 << log2n
+    v, ref = G[e + "synth_values"], G[e + "synth_audio"]
+    es = pkg.HipES(parents, offspring, synth_kind=KIND[d], audio_log2=log2n, param_max=PMAX[d], workgroup_size=wg)
+    try:
+        pv = np.zeros((p, d), np.float32)
+        pv[: len(v)] = v
+        es.write_population(pv, np.full((p, d), 0.1, np.float32), np.zeros(p, np.float32))
+        es.set_synth_arithmetic(pkg.capi.ARITH_DEVICE_KERNELS)
+        es.synthesise()
+        assert np.array_equal(es.read_audio()[: len(v)], ref)
+        es.set_synth_arithmetic(pkg.capi.ARITH_CPU_PATH)
+        es.synthesise()
+        assert not np.array_equal(es.read_audio()[: len(v)], ref)
+    finally:
+        es.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_hip_device_kernel_arithmetic_live_with_lower_bounds(pkg, O, cfg):
+    """The same, live, on unconstrained rows with NON-ZERO parameter minima (whether the scaling min + v (max - min) is fused
+    shows only then) - where the 3-op voice's params[4] offset keeps the phases in range."""
+    import _ocl_ref as R
+    tag, wg, d, log2n, parents, offspring = cfg
+    if not os.path.exists(R.code_object(tag, "exact")):
+        pytest.skip("oracle/_ref holds no code objects (python oracle/build_ref_ocl.py needs /root/reference)")
+    p, n = parents + offspring, 1 << log2n
+    rng = np.random.default_rng(77 + d)
+    pmax4, pmin4 = [3520.0, 8.0, 3520.0, 1.0], [27.5, 0.3, 55.0, 0.1]
+    pmax = {4: pmax4, 6: [3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0], 12: pmax4 * 3}[d]
+    pmin = {4: pmin4, 6: [27.5, 0.3, 55.0, 0.2, 110.0, 0.1], 12: pmin4 * 3}[d]
+    pv = np.zeros((2, p, d), np.float32)
+    pv[0] = rng.random((p, d), dtype=np.float32)
+    table = np.concatenate([O.wavetable(), np.zeros(64, np.float32)])
+    prog = R.RefProgram(tag, "exact")
+    bufs = [R.DeviceBuffer(nbytes=p * n * 4), R.DeviceBuffer(pv), R.DeviceBuffer(np.array(pmin, np.float32)), R.DeviceBuffer(np.array(pmax, np.float32)),
+            R.DeviceBuffer(np.zeros(1, np.uint32)), R.DeviceBuffer(table)]
+    es = pkg.HipES(parents, offspring, synth_kind=KIND[d], audio_log2=log2n, param_min=pmin[:4] if d == 12 else pmin,
+                   param_max=pmax[:4] + [0.0] * 8 if d == 12 else pmax, workgroup_size=wg)
+    try:
+        prog.launch(R.RefGenerationLoop.SYNTH[d], p, wg, bufs)
+        ref = bufs[0].read(np.float32, (p, n))
+        es.write_population(pv[0], np.full((p, d), 0.1, np.float32), np.zeros(p, np.float32))
+        es.set_synth_arithmetic(pkg.capi.ARITH_DEVICE_KERNELS)
+        es.synthesise()
+        audio = es.read_audio()
+        bad = np.nonzero((audio != ref).any(axis=1))[0]
+        assert len(bad) == 0, f"{len(bad)} of {p} rows differ, first {bad[:5]}"
+        for r in range(0, p, 29):
+            assert np.array_equal(O.synth_ocl(KIND[d], pv[0, r], np.array(pmin, np.float32), np.array(pmax, np.float32), n, table, 1), ref[r])
+    finally:
+        es.close()
+        for b in bufs:
+            b.free()
+        prog.unload()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,log2n,parents,offspring", [(0, 10, 64, 192), (1, 11, 16, 16), (2, 10, 32, 96), (0, 10, 4096 + 32, 12288 + 96)])
+def test_generation_loops_with_device_kernel_arithmetic(pkg, O, kind, log2n, parents, offspring):
+    """Both generation loops in SOTS_ARITH_DEVICE_KERNELS mode: the fused loop equals the stage-separated one bit for bit,
+    the audio it leaves behind is the device-kernel voice of the final population, and the populations differ from a
+    default-arithmetic run's (the mode is really in the loop).  The 4-op voice is refused."""
+    pmax = {0: [3520.0, 8.0, 3520.0, 1.0], 1: [3520.0, 8.0, 3520.0, 8.0, 3520.0, 8.0], 2: [3520.0, 8.0, 3520.0, 1.0] + [0.0] * 8}[kind]
+    d = {0: 4, 1: 6, 2: 12}[kind]
+    runs = [pkg.HipES(parents, offspring, synth_kind=kind, audio_log2=log2n, param_max=pmax) for _ in range(3)]
+    a, b, c = runs
+    try:
+        vals = {0: [1450.0 / 3520.0, 3.0 / 8.0, 200.0 / 3520.0, 1.0], 1: [0.87, 0.25, 0.85, 0.19, 0.89, 0.125],
+                2: [0.41, 0.375, 0.057, 1.0, 0.2, 0.5, 0.11, 0.7, 0.6, 0.1, 0.3, 0.4]}[kind]
+        tgt = O.synth(kind, vals, [0.0] * d, pmax, a.N)
+        for es in runs:
+            es.set_target_audio(tgt)
+            es.init_population(0)
+        a.set_synth_arithmetic(pkg.capi.ARITH_DEVICE_KERNELS), b.set_synth_arithmetic(pkg.capi.ARITH_DEVICE_KERNELS)
+        for _ in range(3):
+            a.execute_generation()
+        b.execute_generations(3)
+        c.execute_generations(3)
+        pa, pb, pc = a.read_population(), b.read_population(), c.read_population()
+        for x, y in zip(pa, pb):
+            assert np.array_equal(x, y)
+        assert not np.array_equal(pa[2], pc[2])
+        # the audio buffer after the fused loop: the synthesis of the population BEFORE the last sort; re-synthesise the sorted one
+        b.synthesise()
+        audio = b.read_audio()
+        table = np.concatenate([O.wavetable(), np.zeros(64, np.float32)])
+        pm = np.array(pmax[:4] * 3 if kind == 2 else pmax, np.float32)
+        for r in (0, 1, a.P // 2, a.P - 1):
+            assert np.array_equal(audio[r], O.synth_ocl(kind, pb[0][r], np.zeros(d, np.float32), pm, a.N, table, 1)), f"row {r}"
+    finally:
+        for es in runs:
+            es.close()
+    es4 = pkg.HipES(32, 96, synth_kind=3, audio_log2=10, param_max=[3520.0, 8.0] * 4)
+    with pytest.raises(pkg.capi.SotsError):
+        es4.set_synth_arithmetic(pkg.capi.ARITH_DEVICE_KERNELS)
+    es4.close()
