@@ -641,6 +641,16 @@ def main(argv=None):
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.synth, args.log2n, target, max_threads=args.cpu_threads)
+        # a RECORD, not a measurement of this run: what the reference's own device kernels (kernels/ocl_program.cl compiled as
+        # it stands, tests/ref_kernels_time.py) took on an MI355X at configs[2] - the reference publishes no numbers
+        rec = os.path.join(ROOT, "profiles", "r04_reference_kernels.json")
+        if config_id == 2 and os.path.exists(rec):
+            with open(rec) as f:
+                r = json.load(f)
+            out["reference_kernels_record"] = {"source": "profiles/r04_reference_kernels.json (recorded, not re-run here)",
+                                               "reference_generation_us_without_its_fft": r["reference_generation_us_without_fft"],
+                                               "kernels_us": r["kernels_us"],
+                                               "this_run_generation_us": dt_max / args.steps * 1e6}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -110,6 +110,17 @@ def test_sots_match_cli(tmp_path, O):
         _, _, _, _, gen = read_wav24(tmp_path / "inputGenerated.wav")
         assert len(gen) == 1 << log2n
     cfg["audio"]["audioLengthLog2"] = 10
+    # the reference's OpenCL arithmetic from the JSON block (type.HIP.deviceKernelArithmetic): the search runs on it - against a
+    # target the host synthesised with the CPU path's arithmetic, so the match is close, not exact
+    cfg["type"]["HIP"]["deviceKernelArithmetic"] = True
+    cfg["evolutionary"]["numGenerations"] = 40
+    cfg["evolutionary"]["numParents"], cfg["evolutionary"]["numOffspring"] = 2048, 6144
+    p.write_text(json.dumps(cfg))
+    out = subprocess.run([exe, "-j", str(p)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    fit_dev = float(out.stdout.split("Fitness = ")[1].split()[0])
+    assert 1e-9 < fit_dev < 1e-2
+    cfg["type"]["HIP"].pop("deviceKernelArithmetic")
     # wrong implementation is refused
     cfg["type"]["implementation"] = "OpenCL"
     p.write_text(json.dumps(cfg))
