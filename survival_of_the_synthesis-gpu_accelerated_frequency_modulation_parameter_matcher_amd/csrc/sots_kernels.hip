@@ -1355,21 +1355,38 @@ __device__ __forceinline__ v2f_t xv(float2 a) { return v2f_t{a.x, a.y}; }
 // The packed instructions select the low or high half of each source per result half (op_sel, op_sel_hi) and negate
 // per half (neg_lo, neg_hi); the compiler uses the selects but flips signs of single halves with v_xor and copies, so
 // the few shapes the transform needs are written out.
+#ifndef SOTS_XC_ONE_ASM
+#define SOTS_XC_ONE_ASM 1 // (0: a statement per instruction, rounds 2-3; profiles/r04_experiments.md)
+#endif
 __device__ __forceinline__ v2f_t xc_mul(v2f_t a, v2f_t w)
 {
+#if SOTS_XC_ONE_ASM // both halves in ONE statement: around a statement the compiler pads wait states it cannot rule out (s_nop)
+    v2f_t t;
+    asm("v_pk_mul_f32 %1, %0, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\t"                                              // (a.x w.x, a.y w.x)
+        "v_pk_fma_f32 %0, %0, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(a), "=&v"(t) : "v"(w)); // (-a.y w.y, a.x w.y) + t
+    return a;
+#else
     v2f_t t, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                       // (a.x w.x, a.y w.x)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t)); // (-a.y w.y, a.x w.y) + t
     return r;
+#endif
 }
 __device__ __forceinline__ v2f_t xc_mul_neg_i(v2f_t a) { return v2f_t{a.y, -a.x}; }
 // (-i a) * w = (a.y w.x + a.x w.y, a.y w.y - a.x w.x)
 __device__ __forceinline__ v2f_t xc_mul_negi_w(v2f_t a, v2f_t w)
 {
+#if SOTS_XC_ONE_ASM
+    v2f_t t;
+    asm("v_pk_mul_f32 %1, %0, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"                                  // (a.y w.x, -a.x w.x)
+        "v_pk_fma_f32 %0, %0, %2, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a), "=&v"(t) : "v"(w));               // (a.x w.y, a.y w.y) + t
+    return a;
+#else
     v2f_t t, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));           // (a.y w.x, -a.x w.x)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));        // (a.x w.y, a.y w.y) + t
     return r;
+#endif
 }
 // a + conj(b), a - conj(b)
 __device__ __forceinline__ v2f_t xc_add_conj(v2f_t a, v2f_t b)
@@ -2842,8 +2859,20 @@ __device__ __forceinline__ void x_lane_stage(v2f_t (&x)[E], float sgn, v2f_t wl)
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const v2f_t p = v2f_t{lane_xor_f<H>(x[r].x), lane_xor_f<H>(x[r].y)};
+#if SOTS_XC_ONE_ASM
+        if constexpr (H != 1) { // the butterfly and its twiddle as one statement (see xc_mul)
+            v2f_t t, u = x[r];
+            asm("v_pk_fma_f32 %0, %0, %2, %3\n\t"
+                "v_pk_mul_f32 %1, %0, %4 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                "v_pk_fma_f32 %0, %0, %4, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+                : "+v"(u), "=&v"(t) : "v"(v2f_t{sgn, sgn}), "v"(p), "v"(wl));
+            x[r] = u;
+        } else
+#endif
+        {
         const v2f_t t = x[r] * v2f_t{sgn, sgn} + p;
         x[r] = H == 1 ? t : xc_mul(t, wl);
+        }
         if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0); // (four registers' partner fetches in flight at a time)
     }
 }
