@@ -2800,11 +2800,31 @@ template <int LOG2N> constexpr int x_points() { return (1 << LOG2N) / 2 / kWave;
 #ifndef SOTS_X_WAVES12
 #define SOTS_X_WAVES12 16
 #endif
+#ifndef SOTS_X_SADDR
+#define SOTS_X_SADDR 1
+#endif
+#ifndef SOTS_X_PAIR_SPLIT
+#define SOTS_X_PAIR_SPLIT 1 // both bins of a pair (k, M - k) in one lane (0: every lane its own E bins, rounds 2-3)
+#endif
 // wavefronts (independent rows) per workgroup: what the registers allow (MODE 0, the spectrum writer of the stage-separated
 // path, needs a few more than the fused kernel)
 template <int LOG2N, int MODE = 1> constexpr int x_waves() { return LOG2N >= 13 ? 8 : LOG2N == 12 ? (MODE == 0 ? 12 : SOTS_X_WAVES12) : 16; }
 template <int LOG2N> constexpr bool x_applies() { return LOG2N >= 10 && LOG2N <= 13; }
 
+// target bin of entry (lane l, register r) of k_fft_x's target table.  With SOTS_X_PAIR_SPLIT a lane turns out its own bin
+// for the first register of a pair (RR, R2 = bitrev(E - bitrev(RR))) and its PARTNER lane's bin M - k for the second, so the
+// second register's entry holds that bin's target: the partner is lane l ^ 63 (p' = 63 - p), its bin at r is q + E (63 - p).
+template <int E, int EB>
+__device__ __forceinline__ uint32_t x_target_bin(uint32_t l, uint32_t r)
+{
+    const uint32_t q = __brev(r) >> (32 - EB), pp = __brev(l) >> 26;
+#if SOTS_X_PAIR_SPLIT
+    const uint32_t r2 = q == 0 ? 0u : __brev((uint32_t)E - q) >> (32 - EB);
+    return r2 < r ? q + E * (63u - pp) : q + E * pp;
+#else
+    return q + E * pp;
+#endif
+}
 // f(ic<I>{}) for I = FIRST .. LAST-1 with I a compile-time constant inside f (register arrays are indexed with it)
 template <int FIRST, int LAST, typename F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -2952,7 +2972,7 @@ __global__ __launch_bounds__((WG * kWave), (LOG2N == 12 && MODE == 1 ? SOTS_X_MI
         tw2_s[l * S2 + r] = tw[2u * l * q]; // W_M^{l q} = W_N^{2 l q}
         tws_s[l * S2 + r] = tw[k];          // W_N^k
         if constexpr (WIN) win_s[l * S2 + r] = reinterpret_cast<const float2 *>(window)[l + kWave * r]; // r = input register j here
-        if constexpr (MODE == 1) tgt_s[l * S1 + r] = target[k];
+        if constexpr (MODE == 1) tgt_s[l * S1 + r] = target[x_target_bin<E, EB>(l, r)];
     }
     // per-lane constants of the six lane stages
     const float sg8 = (lane & 8u) ? -1.0f : 1.0f;
@@ -3036,8 +3056,10 @@ __global__ __launch_bounds__((WG * kWave), (LOG2N == 12 && MODE == 1 ? SOTS_X_MI
         const unsigned long long xs_t2 = __builtin_amdgcn_s_memtime();
 #endif
         float acc = 0.0f;
+#if !SOTS_X_PAIR_SPLIT
         v2f_t out_even = v2f_t{0.f, 0.f}; // MODE 0: bins leave two at a time, in bin order
         float2 *__restrict__ dst = MODE == 0 ? reinterpret_cast<float2 *>(spectrum + (size_t)row * (N + 8)) + E * pp : nullptr;
+#endif
         // one bin: register RR of this lane with its partner Z[M - k]
         auto bin2x = [&](auto r_tag) -> v2f_t {
             constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
@@ -3048,6 +3070,21 @@ __global__ __launch_bounds__((WG * kWave), (LOG2N == 12 && MODE == 1 ? SOTS_X_MI
             const v2f_t ee = xc_add_conj(x[RR], zm), dd = xc_sub_conj(x[RR], zm);
             return ee + xc_mul_negi_w(dd, w); // 2 X[k] = (Z[k] + conj Z[M-k]) + W_N^k (-i) (Z[k] - conj Z[M-k])
         };
+#if SOTS_X_PAIR_SPLIT
+        // BOTH bins of the pair (k, M - k) from this lane's Z[k] (register RR) and the partner lane's Z[M - k] (its register
+        // R2): ee and t = W_N^k (-i) dd once, 2 X[k] = ee + t and 2 conj X[M - k] = ee - t.  The partner lane does the same with
+        // ITS register RR and this lane's R2, so every lane still turns out E bins - half of them its partner's - with half
+        // the exchanges and a packed subtraction in place of a second add / subtract / multiply chain.
+        auto pair2x = [&](auto r_tag, v2f_t &xa, v2f_t &xb) {
+            constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = x_bitrev(E - Q, EB);
+            static_assert(Q != 0 && R2 != RR, "registers 0 and bitrev(E / 2) pair with themselves: bin2x");
+            const v2f_t zm = v2f_t{__int_as_float(__builtin_amdgcn_ds_bpermute(addr_flip, __float_as_int(x[R2].x))),
+                                   __int_as_float(__builtin_amdgcn_ds_bpermute(addr_flip, __float_as_int(x[R2].y)))};
+            const v2f_t w = xv(tws_s[lane * S2 + RR]);
+            const v2f_t ee = xc_add_conj(x[RR], zm), t = xc_mul_negi_w(xc_sub_conj(x[RR], zm), w);
+            xa = ee + t, xb = ee - t;
+        };
+#endif
         if constexpr (MODE == 1) {
             // Registers RR and R2 = bitrev(E - bitrev(RR)) need each other and nobody else: the bins are taken in such
             // pairs (this is the summation order, k_fitness_x repeats it), and a pair that is done is free - the NEXT
@@ -3055,28 +3092,78 @@ __global__ __launch_bounds__((WG * kWave), (LOG2N == 12 && MODE == 1 ? SOTS_X_MI
             // its way without a second set of registers.
             // (a wavefront's last row has no successor: it re-reads row 0, which every wavefront of the launch then finds in
             // L2 - loads under `if (more)` cost the compiler its register allocation)
+#if SOTS_X_SADDR
+            // the next row's address as a uniform base (scalar registers) plus a 32-bit lane offset: one address register per
+            // lane instead of a 64-bit pointer and a 64-bit sum per load
+            // (the halves through readfirstlane: otherwise the compiler hoists audio + lane offset out of the loop as a 64-bit
+            // register pair again; the builtin returns a SIGNED int - widen the halves as unsigned)
+            const uint64_t in_next_u = reinterpret_cast<uint64_t>(audio + (size_t)(more ? nxt : 0u) * pitch);
+            const uint32_t in_next_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)in_next_u);
+            const uint32_t in_next_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(in_next_u >> 32));
+            typedef const __attribute__((address_space(1))) char *x_gptr_t; // global, not generic: global_load, not flat_load
+            const x_gptr_t in_next_base = (x_gptr_t)(((uint64_t)in_next_hi << 32) | (uint64_t)in_next_lo);
+            const uint32_t lane_bytes = lane * 8u;
+#else
             const float2 *__restrict__ in_next = reinterpret_cast<const float2 *>(audio + (size_t)(more ? nxt : 0u) * pitch);
+#endif
             static_for<0, E>([&](auto r_tag) {
                 constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
                 if constexpr (R2 >= RR) {
+#if SOTS_X_PAIR_SPLIT
+                    if constexpr (R2 != RR) {
+                        v2f_t xa, xb;
+                        pair2x(ic<RR>{}, xa, xb);
+                        acc += bin_error(make_float2(xa.x, xa.y), tgt_s[lane * S1 + RR], half_scale);
+                        acc += bin_error(make_float2(xb.x, xb.y), tgt_s[lane * S1 + R2], half_scale); // the partner lane's bin M - k: x_target_bin
+                    } else {
+                        const v2f_t xa = bin2x(ic<RR>{});
+                        acc += bin_error(make_float2(xa.x, xa.y), tgt_s[lane * S1 + RR], half_scale);
+                    }
+#else
                     const v2f_t xa = bin2x(ic<RR>{});
                     acc += bin_error(make_float2(xa.x, xa.y), tgt_s[lane * S1 + RR], half_scale);
                     if constexpr (R2 != RR) {
                         const v2f_t xb = bin2x(ic<R2>{});
                         acc += bin_error(make_float2(xb.x, xb.y), tgt_s[lane * S1 + R2], half_scale);
                     }
+#endif
 #ifndef SOTS_X_RECYCLE
 #define SOTS_X_RECYCLE 1
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (SOTS_X_RECYCLE != 0) {
+#if SOTS_X_SADDR
+                        typedef const __attribute__((address_space(1))) v2f_t *x_gv2_t;
+                        x[RR] = __builtin_nontemporal_load((x_gv2_t)(in_next_base + (lane_bytes + 8u * kWave * RR)));
+                        if constexpr (R2 != RR) x[R2] = __builtin_nontemporal_load((x_gv2_t)(in_next_base + (lane_bytes + 8u * kWave * R2)));
+#else
                         x[RR] = x_row_load(in_next + lane + kWave * RR);
                         if constexpr (R2 != RR) x[R2] = x_row_load(in_next + lane + kWave * R2);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             });
         } else
+#if SOTS_X_PAIR_SPLIT
+        static_for<0, E>([&](auto r_tag) { // MODE 0, the fused kernel's pairs: the same values, written where they belong
+            constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
+            if constexpr (R2 >= RR) {
+                float2 *__restrict__ bins = reinterpret_cast<float2 *>(spectrum + (size_t)row * (N + 8));
+                const uint32_t k = E * pp + Q;
+                if constexpr (R2 != RR) {
+                    v2f_t xa, xb;
+                    pair2x(ic<RR>{}, xa, xb);
+                    bins[k] = make_float2(0.5f * xa.x, 0.5f * xa.y);
+                    bins[M - k] = make_float2(0.5f * xb.x, -0.5f * xb.y);
+                } else {
+                    const v2f_t xa = bin2x(ic<RR>{});
+                    bins[k] = make_float2(0.5f * xa.x, 0.5f * xa.y);
+                }
+            }
+            if constexpr (RR % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+#else
         static_for<0, E>([&](auto i_tag) {
             // MODE 0 walks the bins in order
             constexpr int I = decltype(i_tag)::value, RR = MODE == 0 ? x_bitrev(I, EB) : I;
@@ -3096,6 +3183,7 @@ __global__ __launch_bounds__((WG * kWave), (LOG2N == 12 && MODE == 1 ? SOTS_X_MI
             }
             if constexpr (I % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         });
+#endif
         if constexpr (MODE == 0) {
             // the Nyquist bin X[M] = Re Z0 - Im Z0, from Z0 itself: lane 0 still holds it in register 0
             if (lane == 0) reinterpret_cast<float2 *>(spectrum + (size_t)row * (N + 8))[M] = make_float2(x[0].x - x[0].y, 0.0f);
@@ -3232,7 +3320,13 @@ __global__ __launch_bounds__(x_waves<LOG2N>() * kWave) void k_fitness_x(const fl
             constexpr int RR = decltype(r_tag)::value, Q = x_bitrev(RR, EB), R2 = Q == 0 ? 0 : x_bitrev(E - Q, EB);
             if constexpr (R2 >= RR) {
                 acc += bin_error(src[Q], target[E * pp + Q], inv_n * inv_wf);
+#if SOTS_X_PAIR_SPLIT
+                // the pair's second bin is the PARTNER lane's: M - k (k_fft_x's pair2x)
+                if constexpr (R2 != RR)
+                    acc += bin_error(reinterpret_cast<const float2 *>(spectrum + (size_t)row * (N + 8))[N / 2 - (E * pp + Q)], target[N / 2 - (E * pp + Q)], inv_n * inv_wf);
+#else
                 if constexpr (R2 != RR) acc += bin_error(src[x_bitrev(R2, EB)], target[E * pp + x_bitrev(R2, EB)], inv_n * inv_wf);
+#endif
             }
         });
         acc = wave_sum(acc);
@@ -3253,7 +3347,7 @@ __global__ __launch_bounds__(256) void k_x_tables(float *__restrict__ image, con
         tw2_s[l * S2 + r] = tw[2u * l * q];
         tws_s[l * S2 + r] = tw[k];
         win_s[l * S2 + r] = reinterpret_cast<const float2 *>(window)[l + kWave * r];
-        tgt_s[l * S1 + r] = target[k];
+        tgt_s[l * S1 + r] = target[x_target_bin<E, EB>(l, r)];
     }
 }
 #pragma clang fp contract(off)
