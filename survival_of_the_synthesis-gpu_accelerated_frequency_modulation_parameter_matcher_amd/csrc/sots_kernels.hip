@@ -2786,8 +2786,10 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_rank_scatter(const uint32_t
 //      (both as fma(own, +-1, partner) times a per-lane constant).  Lane l ends with p = bitrev6(l).
 // So lane l, register r holds Z[k], k = bitrev(r) + E bitrev6(l): E consecutive bins per lane.  The real-input
 // split needs Z[M - k]: register bitrev(E - q) of lane l ^ 63 (q >= 1) - one ds_bpermute per dword - and every
-// lane turns its own E bins into squared errors (no pair is computed twice).  Window, step-2 twiddles, split
-// twiddles and target are laid out per (lane, register) in LDS once per workgroup (61 KiB, read as 16-byte words).
+// lane turns E bins into squared errors: for half of its registers BOTH bins of the pair (k, M - k), its own and its
+// partner lane's (round 4, pair2x: the pair's sum and twiddled difference are worked out once, not once in each of the two
+// lanes).  Window, step-2 twiddles, split twiddles and target are laid out per (lane, register) in LDS once per workgroup
+// (61 KiB, read as 16-byte words).
 // ------------------------------------------------------------------------------------
 #pragma clang fp contract(on)
 constexpr int x_bitrev(int v, int bits)
@@ -3093,10 +3095,11 @@ __global__ __launch_bounds__((WG * kWave), (LOG2N == 12 && MODE == 1 ? SOTS_X_MI
             // (a wavefront's last row has no successor: it re-reads row 0, which every wavefront of the launch then finds in
             // L2 - loads under `if (more)` cost the compiler its register allocation)
 #if SOTS_X_SADDR
-            // the next row's address as a uniform base (scalar registers) plus a 32-bit lane offset: one address register per
-            // lane instead of a 64-bit pointer and a 64-bit sum per load
-            // (the halves through readfirstlane: otherwise the compiler hoists audio + lane offset out of the loop as a 64-bit
-            // register pair again; the builtin returns a SIGNED int - widen the halves as unsigned)
+            // the next row's address as a uniform base (scalar registers: audio + row offset) plus the lane's byte offset, instead
+            // of the loop-invariant 64-bit pointer audio + lane offset plus a uniform row offset: with the pair split that pointer
+            // was the one value too many for the 128 registers (an 8-byte spill, reloaded once per row; 130 against 127 us)
+            // (the builtin returns a SIGNED int - the halves are widened as unsigned: the first attempt sign-extended the low
+            // half and faulted on rows whose address has bit 31 set)
             const uint64_t in_next_u = reinterpret_cast<uint64_t>(audio + (size_t)(more ? nxt : 0u) * pitch);
             const uint32_t in_next_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)in_next_u);
             const uint32_t in_next_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(in_next_u >> 32));
